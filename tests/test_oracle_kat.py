@@ -1,0 +1,456 @@
+"""Pins the CPU oracle against every known-answer test, size/choice assert and round-trip input
+the reference crate's own in-source tests hold (data in tests/golden/reference_kats.json, plus
+the structural asserts cited inline as file:line of the reference)."""
+import numpy as np
+import pytest
+
+
+def _u64s(xs):
+    return np.array([int(x, 16) if isinstance(x, str) and x.startswith("0x") else int(x) for x in xs],
+                    dtype=np.uint64)
+
+
+# ---- nibblepacking.rs octet KATs -------------------------------------------------------
+
+def test_nibble_pack8_literal_bytes(oracle, kats):
+    for k in kats["nibble_pack8"]:
+        got = oracle.nibble_pack8(_u64s(k["inputs"]))
+        assert list(got) == k["expected"], k["src"]
+
+
+def test_nibble_unpack8_literal(oracle, kats):
+    for k in kats["nibble_unpack8"]:
+        vals, used = oracle.nibble_unpack8(bytes(k["encoded"]))
+        assert list(vals) == list(_u64s(k["values"])), k["src"]
+        assert len(k["encoded"]) - used == k["remainder"], k["src"]
+
+
+def test_nibble_unpack8_too_short(oracle, kats):
+    for k in kats["nibble_unpack8_errors"]:
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.nibble_unpack8(bytes(k["encoded"]))
+        assert e.value.code == oracle.NOT_ENOUGH_SPACE, k["src"]
+
+
+def test_pack_unpack_u64_plain_and_delta(oracle, kats):
+    for k in kats["roundtrip_u64"]:
+        vals = np.array(k["values"], dtype=np.uint64)
+        enc = oracle.pack_u64(vals)
+        out, used = oracle.unpack_u64(enc, len(vals))
+        assert used == len(enc)                      # res.unwrap().len() == 0
+        assert list(out[:len(vals)]) == list(vals)
+        enc = oracle.pack_u64_delta(vals)
+        out, used = oracle.unpack_u64_delta(enc, len(vals))
+        assert used == len(enc)
+        assert list(out[:len(vals)]) == list(vals)
+
+
+def test_pack_unpack_f64_xor(oracle, kats):
+    for k in kats["roundtrip_f64_xor"]:
+        vals = np.array(k["values"], dtype=np.float64)
+        enc = oracle.pack_f64_xor(vals)
+        out, used = oracle.unpack_f64_xor(enc, len(vals))
+        assert used == len(enc)
+        assert out[:len(vals)].tobytes() == vals.tobytes()
+
+
+def test_u32_unpack_roundtrips(oracle, kats):
+    for k in kats["u32_unpack_roundtrip"]:
+        vals = np.array(k["values"], dtype=np.uint32)
+        enc = oracle.pack_u64(vals.astype(np.uint64))
+        first, used = oracle.unpack8_u32(enc)
+        if "remainder_after_first" in k:
+            assert len(enc) - used == k["remainder_after_first"], k["src"]
+        n1 = min(8, len(vals))
+        assert list(first[:n1]) == list(vals[:n1]), k["src"]
+        if len(vals) > 8:
+            second, _ = oracle.unpack8_u32(enc[used:])
+            assert list(second[:len(vals) - 8]) == list(vals[8:]), k["src"]
+
+
+def test_proptest_regression_inputs(oracle, kats):
+    for k in kats["proptest_regressions"]:
+        if k["kind"] == "octet_u64":
+            v = _u64s(k["values"])
+            enc = oracle.nibble_pack8(v, cap=256)
+            out, _ = oracle.nibble_unpack8(enc + bytes(256 - len(enc)))
+            assert list(out) == list(v), k["src"]
+        elif k["kind"] == "stream_u32":
+            v = np.array(k["values"], dtype=np.uint32)
+            enc = oracle.pack_u64(v.astype(np.uint64))
+            out, _ = oracle.unpack8_u32(enc + bytes(2048 - len(enc)))
+            assert list(out[:len(v)]) == list(v), k["src"]
+        elif k["kind"] == "delta_stream_u64":
+            v = _u64s(k["values"])
+            enc = oracle.pack_u64_delta(v)
+            out, _ = oracle.unpack_u64_delta(enc + bytes(512), len(v))
+            assert list(out[:len(v)]) == list(v), k["src"]
+
+
+def test_property_pack_unpack_identity(oracle):
+    """nibblepacking.rs:769-776 and nibblepack_simd.rs:720-741 as seeded random sweeps."""
+    rng = np.random.default_rng(1234)
+    for _ in range(3000):
+        nbits = int(rng.integers(4, 64))
+        chance = rng.uniform(0.2, 0.8)
+        v = rng.integers(0, 1 << nbits, size=8, dtype=np.uint64)
+        v[rng.random(8) < chance] = 0
+        enc = oracle.nibble_pack8(v, cap=256)
+        out, used = oracle.nibble_unpack8(enc)
+        assert used == len(enc)
+        assert list(out) == list(v)
+    for _ in range(3000):
+        nbits = int(rng.integers(4, 30))
+        chance = rng.uniform(0.1, 0.6)
+        v = rng.integers(0, 1 << nbits, size=8, dtype=np.uint64)
+        v[rng.random(8) < chance] = 0
+        enc = oracle.nibble_pack8(v, cap=256)
+        out, used = oracle.unpack8_u32(enc)
+        assert used == len(enc)
+        assert list(out) == list(v.astype(np.uint32))
+
+
+def test_u32_octet_error_paths(oracle):
+    # nibblepack_simd.rs:515, :523, :556
+    for buf, code in [(b"", oracle.NOT_ENOUGH_SPACE), (b"\x01\x00", oracle.NOT_ENOUGH_SPACE),
+                      (b"\x01\x80\x00\x00\x00\x00\x00", oracle.INVALID_FORMAT),
+                      (b"\xff\x70\x00\x00", oracle.NOT_ENOUGH_SPACE)]:
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.unpack8_u32(buf)
+        assert e.value.code == code
+
+
+def test_tail_quirk_mode_documents_reference_bug(oracle):
+    """The reference's tail fallback (nibblepack_simd.rs:433-450) yields zeros for 5..8-nibble octets
+    within the last 33 bytes of a slice; the oracle reproduces it only when asked to."""
+    v = np.array([0x12345678] * 8, dtype=np.uint64)
+    enc = oracle.nibble_pack8(v)
+    assert len(enc) == 34
+    out, _ = oracle.unpack8_u32(enc[:34])
+    assert list(out) == [0x12345678] * 8
+    v[7] = 0
+    enc = oracle.nibble_pack8(v)          # 30 bytes < 34
+    oracle.lib().ocv_set_ref_tail_quirk(1)
+    try:
+        out, _ = oracle.unpack8_u32(enc)
+        assert list(out) == [0] * 8
+    finally:
+        oracle.lib().ocv_set_ref_tail_quirk(0)
+    out, _ = oracle.unpack8_u32(enc)
+    assert list(out) == [0x12345678] * 7 + [0]
+
+
+# ---- section.rs ---------------------------------------------------------------------------
+
+def test_fixedsect_iterator_null_then_np(oracle):
+    # section.rs:942-973
+    data = np.arange(256, dtype=np.uint64)
+    buf = oracle.section_write(oracle.U64, data, kind=oracle.SECT_NULL)
+    assert len(buf) == 1
+    buf += oracle.section_write(oracle.U64, data, kind=oracle.SECT_NP)
+    k0, n0 = oracle.section_parse(oracle.U64, buf)
+    assert (k0, n0) == (oracle.SECT_NULL, 1)
+    k1, n1 = oracle.section_parse(oracle.U64, buf[1:])
+    assert k1 == oracle.SECT_NP and n1 == len(buf) - 1
+    assert list(oracle.section_decode(oracle.U64, buf[1:])) == list(data)
+
+
+def test_np_write_error_no_room(oracle):
+    # section.rs:926-939
+    data = np.arange(256, dtype=np.uint64)
+    for cap in (2, 100):
+        with pytest.raises(oracle.OracleError) as e:
+            oracle.section_write(oracle.U64, data, kind=oracle.SECT_NP, cap=cap)
+        assert e.value.code == oracle.NOT_ENOUGH_SPACE
+
+
+def test_u32_section_write_and_decode(oracle):
+    # section.rs:976-986
+    data = np.arange(256, dtype=np.uint32)
+    buf = oracle.section_write(oracle.U32, data, kind=oracle.SECT_NP)
+    assert list(oracle.section_decode(oracle.U32, buf)) == list(data)
+
+
+def test_delta_write_and_decode(oracle):
+    # section.rs:989-1017
+    base = 1731300000123
+    data = np.arange(256, dtype=np.uint64) + np.uint64(base)
+    buf = oracle.section_write(oracle.U64, data, kind=oracle.SECT_DELTA)
+    kind, nb = oracle.section_parse(oracle.U64, buf)
+    assert kind == oracle.SECT_DELTA and nb < 350
+    assert list(oracle.section_decode(oracle.U64, buf)) == list(data)
+    b, nbits = oracle.section_delta_info(oracle.U64, buf)
+    assert b == base and 2 ** nbits == 256
+    data32 = np.arange(256, dtype=np.uint32) + np.uint32(100_000)
+    buf = oracle.section_write(oracle.U32, data32, kind=oracle.SECT_DELTA)
+    kind, nb = oracle.section_parse(oracle.U32, buf)
+    assert kind == oracle.SECT_DELTA and nb < 350
+    assert list(oracle.section_decode(oracle.U32, buf)) == list(data32)
+    b, nbits = oracle.section_delta_info(oracle.U32, buf)
+    assert b == 100_000 and 2 ** nbits == 256
+    assert buf[8:12] == b"\0\0\0\0"          # u32 base slot: upper 4 bytes stay zero
+
+
+def test_const_write_and_decode(oracle):
+    # section.rs:1020-1030
+    data = np.full(256, 400, dtype=np.uint64)
+    buf = oracle.section_write(oracle.U64, data, kind=oracle.SECT_CONST)
+    kind, nb = oracle.section_parse(oracle.U64, buf)
+    assert kind == oracle.SECT_CONST and nb == 9
+    assert list(oracle.section_decode(oracle.U64, buf)) == list(data)
+
+
+def test_autoencoder_choices(oracle):
+    # section.rs:1033-1071
+    cases = [(oracle.U64, np.full(256, 23000, dtype=np.uint64), oracle.SECT_CONST),
+             (oracle.U64, np.zeros(256, dtype=np.uint64), oracle.SECT_NULL),
+             (oracle.U32, np.arange(256, dtype=np.uint32), oracle.SECT_NP),
+             (oracle.U32, np.arange(10000, 10256, dtype=np.uint32), oracle.SECT_DELTA)]
+    for et, data, want in cases:
+        buf = oracle.section_write(et, data)
+        kind, _ = oracle.section_parse(et, buf)
+        assert kind == want
+        assert list(oracle.section_decode(et, buf)) == list(data)
+
+
+def test_xor_write_and_decode(oracle):
+    # section.rs:1074-1086
+    data = (np.arange(256, dtype=np.float32) / np.float32(1.3)).astype(np.float32)
+    buf = oracle.section_write(oracle.F32, data)
+    kind, nb = oracle.section_parse(oracle.F32, buf)
+    assert kind == oracle.SECT_XOR and nb == len(buf)
+    assert oracle.section_decode(oracle.F32, buf).tobytes() == data.tobytes()
+
+
+def test_f32_xor_autoencode(oracle):
+    # section.rs:1089-1127
+    cases = [(np.full(256, 3.5, dtype=np.float32), oracle.SECT_CONST),
+             (np.zeros(256, dtype=np.float32), oracle.SECT_NULL),
+             ((np.arange(256, dtype=np.float32) / np.float32(1.6)).astype(np.float32), oracle.SECT_XOR)]
+    for data, want in cases:
+        buf = oracle.section_write(oracle.F32, data)
+        kind, _ = oracle.section_parse(oracle.F32, buf)
+        assert kind == want
+        assert oracle.section_decode(oracle.F32, buf).tobytes() == data.tobytes()
+
+
+def test_f32_stats_fold_order(oracle):
+    """section.rs:473-480: min_by keeps the first of equals, max_by the last; NaN compares Equal."""
+    d = np.full(256, 5.0, dtype=np.float32)
+    d[1] = np.nan
+    buf = oracle.section_write(oracle.F32, d)        # min = max = 5 → lossy Const section
+    assert buf[0] == oracle.SECT_CONST
+    d = np.zeros(256, dtype=np.float32)
+    d[3] = -0.0
+    assert oracle.section_write(oracle.F32, d) == b"\x00"
+    d = np.full(256, 5.0, dtype=np.float32)
+    d[255] = np.nan                                  # max = NaN → min != max → Xor
+    assert oracle.section_write(oracle.F32, d)[0] == oracle.SECT_XOR
+    d = np.full(256, 5.0, dtype=np.float32)
+    d[0] = np.nan                                    # min = NaN
+    assert oracle.section_write(oracle.F32, d)[0] == oracle.SECT_XOR
+
+
+def test_section_type_errors(oracle):
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.section_parse(oracle.U32, b"\x02\x00\x00")
+    assert e.value.code == oracle.INVALID_SECTION_TYPE
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.section_parse(oracle.U32, b"")
+    assert e.value.code == oracle.INPUT_TOO_SHORT
+    xor = oracle.section_write(oracle.F32, (np.arange(256) / 1.3).astype(np.float32))
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.section_decode(oracle.U32, xor)
+    assert e.value.code == oracle.INVALID_FORMAT
+    np_sec = oracle.section_write(oracle.U32, np.arange(256, dtype=np.uint32))
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.section_decode(oracle.F32, np_sec)
+    assert e.value.code == oracle.INVALID_FORMAT
+
+
+# ---- vector.rs ----------------------------------------------------------------------------
+
+def test_hand_derived_whole_vectors(oracle, kats):
+    tmap = {"u32": oracle.U32, "u64": oracle.U64, "f32": oracle.F32}
+    for k in kats["hand_derived_vectors"]:
+        et = tmap[k["type"]]
+        got = oracle.encode_all(et, np.array(k["values"], dtype=oracle.NP_DTYPE[et]))
+        assert list(got) == k["expected"], k["src"]
+
+
+def test_append_u64_nonulls(oracle):
+    # vector.rs:564-598
+    n = 500
+    data = np.arange(n, dtype=np.uint64)
+    a = oracle.Appender(oracle.U64, 1024)
+    rb = a.reader_bytes()
+    assert oracle.reader_num_elements(rb)[0] == 0 and len(oracle.reader_sections(oracle.U64, rb)) == 0
+    a.append_many(data)
+    rb = a.reader_bytes()
+    assert oracle.reader_num_elements(rb)[0] == 256 and len(oracle.reader_sections(oracle.U64, rb)) == 1
+    vec = a.finish(n)
+    assert oracle.reader_num_elements(vec)[0] == n
+    kinds = oracle.reader_sections(oracle.U64, vec)
+    assert len(kinds) == 2 and (kinds == 0).sum() == 0
+    assert list(oracle.iterate(oracle.U64, vec)) == list(data)
+
+
+def test_append_u64_mixed_nulls(oracle):
+    # vector.rs:601-634
+    d1 = np.arange(100, dtype=np.uint64)
+    nulls = (256 - 100) + 256 + 50
+    d2 = np.arange(50, dtype=np.uint64)
+    total = 100 + 50 + nulls
+    all_data = np.concatenate([d1, np.zeros(nulls, dtype=np.uint64), d2])
+    a = oracle.Appender(oracle.U64, 1024)
+    a.append_many(d1)
+    a.append_nulls(nulls)
+    a.append_many(d2)
+    vec = a.finish(total)
+    assert oracle.reader_num_elements(vec) == (total, 1)
+    kinds = oracle.reader_sections(oracle.U64, vec)
+    assert len(kinds) == 3 and (kinds == 0).sum() == 1
+    assert list(oracle.iterate(oracle.U64, vec)) == list(all_data)
+
+
+def test_append_u64_mixed_nulls_grow(oracle):
+    # vector.rs:637-666
+    d1 = np.arange(300, dtype=np.uint64)
+    nn = 350
+    total = (300 + nn) * 2
+    z = np.zeros(nn, dtype=np.uint64)
+    all_data = np.concatenate([d1, z, d1, z])
+    a = oracle.Appender(oracle.U64, 300)
+    for part in (d1, None, d1, None):
+        if part is None:
+            a.append_nulls(nn)
+        else:
+            a.append_many(part)
+    vec = a.finish(total)
+    assert oracle.reader_num_elements(vec)[0] == total
+    kinds = oracle.reader_sections(oracle.U64, vec)
+    assert len(kinds) == 6 and (kinds == 0).sum() == 2
+    assert list(oracle.iterate(oracle.U64, vec)) == list(all_data)
+
+
+def test_append_u32_and_filter(oracle):
+    # vector.rs:669-710
+    n = 400
+    a = oracle.Appender(oracle.U32, 1024)
+    a.append_many((np.arange(n, dtype=np.uint32) % 4) + 1)
+    vec = a.finish(n)
+    assert oracle.reader_num_elements(vec)[0] == n and len(oracle.reader_sections(oracle.U32, vec)) == 2
+    assert oracle.filter_count(oracle.U32, vec, 3) == n // 4
+    nonnulls = 300
+    total = nonnulls * 2 + 400
+    part = (np.arange(nonnulls, dtype=np.uint32) % 4) + 1
+    a.append_many(part)
+    a.append_nulls(400)
+    a.append_many(part)
+    vec = a.finish(total)
+    assert oracle.reader_num_elements(vec)[0] == total
+    assert oracle.filter_count(oracle.U32, vec, 3) == nonnulls * 2 // 4
+    dec = oracle.decode_to_vec(oracle.U32, vec)
+    assert len(dec) % 256 == 0
+    assert list(dec[:total]) == list(oracle.iterate(oracle.U32, vec))
+
+
+def test_append_u32_large_sparse_vector(oracle):
+    # vector.rs:713-726
+    a = oracle.Appender(oracle.U32, 4096)
+    for _ in range(10):
+        a.append_nulls(9999)
+        a.append(2)
+    assert a.num_elements() == 100000
+    vec = a.finish(100000)
+    assert oracle.reader_num_elements(vec)[0] == 100000
+
+
+def test_read_wrong_type_error(oracle):
+    # vector.rs:729-739
+    vec = oracle.encode_all(oracle.U32, (np.arange(400, dtype=np.uint32) % 4) + 1)
+    rc, detail = oracle.reader_check(oracle.U64, vec)
+    assert rc == oracle.WRONG_VECTOR_TYPE and detail == 0x11
+
+
+def test_append_f32_decode(oracle):
+    # vector.rs:742-755
+    n = 280
+    data = (np.arange(n, dtype=np.float32) / np.float32(2.8)).astype(np.float32)
+    vec = oracle.encode_all(oracle.F32, data)
+    assert oracle.reader_num_elements(vec)[0] == n
+    dec = oracle.decode_to_vec(oracle.F32, vec)
+    assert dec[:n].tobytes() == data.tobytes()
+
+
+def test_finish_invalid_num_rows(oracle):
+    a = oracle.Appender(oracle.U32, 1024)
+    a.append_many(np.arange(10, dtype=np.uint32))
+    with pytest.raises(oracle.OracleError) as e:
+        a.finish(5)                                  # vector.rs:346
+    assert e.value.code == oracle.INVALID_NUM_ROWS
+
+
+def test_readme_sink_stack(oracle):
+    # README.md:38, :58-65: XorSink → AddConstSink(2.5) → VecSink
+    vec = oracle.encode_all(oracle.F32, np.array([1.0, 1.5, 2.0, 2.5], dtype=np.float32))
+    dec = oracle.decode_to_vec(oracle.F32, vec, add_base=2.5)
+    assert list(dec[:4]) == [3.5, 4.0, 4.5, 5.0]
+    assert len(dec) == 256 and np.all(dec[4:] == 2.5)
+
+
+def test_addconst_null_section_forwards_base_bits(oracle):
+    # sink.rs:314-317: a Null section through AddConstSink(-0.0) yields -0.0, not 0.0 + -0.0 = +0.0
+    vec = oracle.encode_all(oracle.F32, np.zeros(256, dtype=np.float32))
+    dec = oracle.decode_to_vec(oracle.F32, vec, add_base=-0.0)
+    assert np.all(dec.view(np.uint32) == 0x80000000)
+
+
+# ---- filter.rs ----------------------------------------------------------------------------
+
+def test_filter_u64_equals_positions(oracle):
+    # filter.rs:332-348
+    n = 400
+    vec = oracle.encode_all(oracle.U64, (np.arange(n, dtype=np.uint64) % 4) + 1)
+    cnt, masks = oracle.filter_count(oracle.U64, vec, 3, return_masks=True)
+    pos = oracle.match_positions(masks, ref_quirk=True)
+    assert cnt == n // 4 and list(pos) == list(range(2, n, 4))
+
+
+def test_filter_u32_oneof_positions(oracle):
+    # filter.rs:351-371
+    n = 400
+    vec = oracle.encode_all(oracle.U32, (np.arange(n, dtype=np.uint32) % 12) + 1)
+    cnt, masks = oracle.filter_count(oracle.U32, vec, [3, 5], return_masks=True)
+    pos = oracle.match_positions(masks, ref_quirk=True)
+    exp = [p for i in range(2, n, 12) for p in (i, i + 2)][:67]
+    assert cnt == 67 and list(pos) == exp
+
+
+def test_match_positions_quirk_vs_true(oracle):
+    # filter.rs:307-317: pos is not advanced over all-zero mask words
+    v = np.zeros(256, dtype=np.uint32)
+    v[0] = 7
+    v[200] = 7
+    vec = oracle.encode_all(oracle.U32, v)
+    _, masks = oracle.filter_count(oracle.U32, vec, 7, return_masks=True)
+    assert list(oracle.match_positions(masks, ref_quirk=False)) == [0, 200]
+    assert list(oracle.match_positions(masks, ref_quirk=True)) == [0, 40]
+
+
+def test_filter_counts_padding_when_predicate_matches_zero(oracle):
+    vec = oracle.encode_all(oracle.U32, np.array([0, 1, 0, 2], dtype=np.uint32))
+    assert oracle.filter_count(oracle.U32, vec, 0) == 254
+    vec = oracle.encode_all(oracle.F32, np.array([0.0, 1.0, -0.0, 2.0], dtype=np.float32))
+    assert oracle.filter_count(oracle.F32, vec, -0.0) == 254
+
+
+def test_multi_vector_filter(oracle):
+    # filter.rs:239-286 as used by benches/bench.rs:192-203
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 4, size=1000).astype(np.uint32)
+    b = rng.integers(0, 3, size=1000).astype(np.uint32)
+    va, vb = oracle.encode_all(oracle.U32, a), oracle.encode_all(oracle.U32, b)
+    want = int(((a == 3) & (b == 2)).sum())
+    assert oracle.multi_filter_count(oracle.U32, [va, vb], [3, 2]) == want
+    assert oracle.multi_filter_count(oracle.U32, [vb, va], [2, 3]) == want
