@@ -1,0 +1,103 @@
+"""ctypes binding of the C ABI in include/cvec.h (lib/libcvec_hip.so).
+
+There is no CPU fallback: if the HIP library is missing every entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcvec_hip.so")
+
+U64, U32, F32 = 0x10, 0x11, 0x12
+PRED_EQ, PRED_ONEOF = 0, 1
+MAX_PRED_VALUES = 16
+RESULT_WORDS = 4
+
+OK = 0
+NOT_ENOUGH_SPACE, INPUT_TOO_SHORT, BAD_OFFSET, INVALID_SECTION_TYPE, INVALID_FORMAT, INVALID_NUM_ROWS, \
+    WRONG_VECTOR_TYPE, SCROLL_ERR = range(1, 9)
+ERR_SECTION_COUNT, ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_WORKSPACE = 100, 101, 102, 103, 104
+
+_NAMES = {0: "Ok", 1: "NotEnoughSpace", 2: "InputTooShort", 3: "BadOffset", 4: "InvalidSectionType",
+          5: "InvalidFormat", 6: "InvalidNumRows", 7: "WrongVectorType", 8: "ScrollErr",
+          100: "SectionCountMismatch", 101: "BadArgument", 102: "HipError", 103: "NoDevice",
+          104: "WorkspaceTooSmall"}
+
+
+class CodingError(Exception):
+    """Mirror of the reference's CodingError enum (src/error.rs:2-11) plus library errors (>= 100)."""
+
+    def __init__(self, code, *detail):
+        self.code = int(code)
+        self.detail = detail
+        super().__init__("%s%s" % (_NAMES.get(self.code, "Error%d" % self.code),
+                                   "(%s)" % ", ".join(map(str, detail)) if detail else ""))
+
+    @property
+    def name(self):
+        return _NAMES.get(self.code, "Unknown")
+
+
+class Pred(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("count", C.c_uint32), ("values", C.c_uint64 * MAX_PRED_VALUES)]
+
+
+class SinkChain(C.Structure):
+    _fields_ = [("add_const", C.c_int32), ("_pad", C.c_int32), ("add_const_bits", C.c_uint64)]
+
+
+class DBatchView(C.Structure):
+    _fields_ = [("etype", C.c_int32), ("_pad", C.c_int32), ("n_vectors", C.c_uint64), ("n_sections", C.c_uint64),
+                ("n_bytes", C.c_uint64), ("d_bytes", C.c_void_p), ("d_byte_off", C.c_void_p),
+                ("d_sec_base", C.c_void_p)]
+
+
+# Every symbol include/cvec.h declares, with its signature.
+SIGNATURES = {
+    "cvec_version": (C.c_char_p, []),
+    "cvec_init": (C.c_int32, [C.c_int]),
+    "cvec_last_hip_error": (C.c_char_p, []),
+    "cvec_status_name": (C.c_char_p, [C.c_int32]),
+    "cvec_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
+    "cvec_sec_base_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64),
+                                      C.c_void_p]),
+    "cvec_filter_count_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_decode_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(SinkChain), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_max_encoded_bytes": (C.c_size_t, [C.c_int32, C.c_uint64, C.c_uint64]),
+    "cvec_encode_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
+    "cvec_encode_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
+    "cvec_filter_count_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Pred),
+                                            C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
+    "cvec_decode_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(SinkChain),
+                                      C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "cvec_encode_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads lib/libcvec_hip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("HIP library %s is missing: run __graft_entry__.build() (or make -C "
+                               "compressed-vec_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, *detail):
+    if status != OK:
+        if status == ERR_HIP:
+            raise CodingError(status, lib().cvec_last_hip_error().decode())
+        raise CodingError(status, *detail)

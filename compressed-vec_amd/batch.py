@@ -1,0 +1,262 @@
+"""Batches of encoded vectors, on the host and resident in MI355X HBM.
+
+A batch is n reference-format vectors stored back to back in one byte blob plus byte_off[n+1].
+Device memory, streams and (for multi-GPU) torch.distributed come from PyTorch; all work on the
+bytes is done by the HIP library through the C ABI (include/cvec.h)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+NP_DTYPE = {N.U64: np.uint64, N.U32: np.uint32, N.F32: np.float32}
+TORCH_DTYPE = {N.U64: torch.int64, N.U32: torch.int32, N.F32: torch.float32}
+WIDTH = {N.U64: 8, N.U32: 4, N.F32: 4}
+FIXED_LEN = 256
+
+
+def etype_of(dtype):
+    """Maps 'u32' / 'u64' / 'f32' (or numpy dtypes, or the header's minor-type byte) to the element type."""
+    if isinstance(dtype, int) and dtype in NP_DTYPE:
+        return dtype
+    if isinstance(dtype, str):
+        key = dtype.lower()
+        if key in ("u32", "uint32"):
+            return N.U32
+        if key in ("u64", "uint64"):
+            return N.U64
+        if key in ("f32", "float32"):
+            return N.F32
+    d = np.dtype(dtype)
+    if d == np.uint32:
+        return N.U32
+    if d == np.uint64:
+        return N.U64
+    if d == np.float32:
+        return N.F32
+    raise ValueError("unsupported element type %r" % (dtype,))
+
+
+def _bits(etype, value):
+    """Raw little-endian bits of a scalar of the element type, as an int."""
+    a = np.array([value], dtype=NP_DTYPE[etype])
+    return int(a.view(np.uint64 if etype == N.U64 else np.uint32)[0])
+
+
+def make_pred(etype, pred):
+    """scalar → EqualsSink predicate, sequence → OneOfSink predicate (reference src/filter.rs:129-177)."""
+    p = N.Pred()
+    if isinstance(pred, (list, tuple, np.ndarray)):
+        vals = list(pred)
+        if not 1 <= len(vals) <= N.MAX_PRED_VALUES:
+            raise N.CodingError(N.ERR_BAD_ARGUMENT, "OneOf takes 1..%d values" % N.MAX_PRED_VALUES)
+        p.kind, p.count = N.PRED_ONEOF, len(vals)
+    else:
+        vals = [pred]
+        p.kind, p.count = N.PRED_EQ, 1
+    for i, v in enumerate(vals):
+        p.values[i] = _bits(etype, v)
+    return p
+
+
+def make_chain(etype, add_const=None):
+    c = N.SinkChain()
+    if add_const is not None:
+        c.add_const = 1
+        c.add_const_bits = _bits(etype, add_const)
+    return c
+
+
+class EncodedBatch:
+    """Host-side batch: `blob` (uint8 array) and `byte_off` (uint64, n+1)."""
+
+    def __init__(self, etype, blob, byte_off):
+        self.etype = etype_of(etype)
+        self.blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.byte_off = np.ascontiguousarray(byte_off, dtype=np.uint64)
+        assert self.byte_off.ndim == 1 and self.byte_off.size >= 1
+
+    @classmethod
+    def from_vectors(cls, etype, vectors):
+        """Concatenates individually encoded vectors (bytes objects)."""
+        lens = np.array([len(v) for v in vectors], dtype=np.uint64)
+        off = np.zeros(len(vectors) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        blob = np.frombuffer(b"".join(bytes(v) for v in vectors), dtype=np.uint8).copy() if len(vectors) else \
+            np.zeros(0, dtype=np.uint8)
+        return cls(etype, blob, off)
+
+    @property
+    def n_vectors(self):
+        return self.byte_off.size - 1
+
+    def vector(self, i):
+        return self.blob[int(self.byte_off[i]):int(self.byte_off[i + 1])].tobytes()
+
+    def to_device(self, device="cuda", stream=None):
+        return DeviceBatch.upload(self, device=device)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceBatch:
+    """A batch resident in HBM: blob, byte_off and sec_base as torch tensors + the C view of them."""
+
+    def __init__(self, etype, d_bytes, d_byte_off, d_sec_base, n_vectors, n_sections, n_bytes):
+        self.etype = etype
+        self.d_bytes, self.d_byte_off, self.d_sec_base = d_bytes, d_byte_off, d_sec_base
+        self.n_vectors, self.n_sections, self.n_bytes = int(n_vectors), int(n_sections), int(n_bytes)
+        self.device = d_bytes.device
+        v = N.DBatchView()
+        v.etype = etype
+        v.n_vectors, v.n_sections, v.n_bytes = self.n_vectors, self.n_sections, self.n_bytes
+        v.d_bytes, v.d_byte_off, v.d_sec_base = d_bytes.data_ptr(), d_byte_off.data_ptr(), d_sec_base.data_ptr()
+        self.view = v
+        self._ws = None
+        self._result = None
+
+    @classmethod
+    def upload(cls, host, device="cuda", pinned=False):
+        """H2D copy of a host batch, then sec_base from the headers on the device."""
+        dev = torch.device(device)
+        n_bytes = int(host.byte_off[-1])
+        # the kernels stage the blob with 16-byte loads: pad the allocation so the last chunk is readable
+        d_bytes = torch.zeros(((n_bytes + 16 + 255) // 256) * 256, dtype=torch.uint8, device=dev)
+        hb = torch.from_numpy(host.blob[:n_bytes])
+        ho = torch.from_numpy(host.byte_off.view(np.int64))
+        if pinned:
+            hb, ho = hb.pin_memory(), ho.pin_memory()
+        d_bytes[:n_bytes].copy_(hb, non_blocking=pinned)
+        d_byte_off = ho.to(dev, non_blocking=pinned)
+        return cls.from_device_tensors(host.etype, d_bytes, d_byte_off, n_bytes)
+
+    @classmethod
+    def from_device_tensors(cls, etype, d_bytes, d_byte_off, n_bytes):
+        n = d_byte_off.numel() - 1
+        d_sec_base = torch.empty(n + 1, dtype=torch.int64, device=d_bytes.device)
+        nsec = C.c_uint64(0)
+        with torch.cuda.device(d_bytes.device):
+            N.check(N.lib().cvec_sec_base_dev(_ptr(d_bytes), _ptr(d_byte_off), n, _ptr(d_sec_base), C.byref(nsec),
+                                              _stream_ptr()))
+        return cls(etype, d_bytes, d_byte_off, d_sec_base, n, nsec.value, n_bytes)
+
+    def download(self):
+        blob = self.d_bytes[:self.n_bytes].cpu().numpy()
+        off = self.d_byte_off.cpu().numpy().view(np.uint64)
+        return EncodedBatch(self.etype, blob, off)
+
+    # -- scratch owned by the batch so that repeated queries allocate nothing ------------------------
+    def workspace(self):
+        if self._ws is None:
+            nbytes = N.lib().cvec_workspace_bytes(self.n_vectors, self.n_sections)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def result_buffer(self):
+        if self._result is None:
+            self._result = torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device=self.device)
+        return self._result
+
+    def section_results(self):
+        """Per-section result words of the last operation (low 16 bits: count, high 16: status), read
+        back from the workspace; for inspecting where a malformed vector stopped."""
+        ws = self.workspace()
+        off = ((self.n_sections + 1) * 8 + 255) // 256 * 256
+        raw = ws[off:off + 4 * self.n_sections].cpu().numpy()
+        return raw.view(np.uint32)
+
+    # -- operations -------------------------------------------------------------------------------------
+    def filter_count_async(self, pred, per_vector=None, status=None, masks=None, result=None):
+        """Enqueues decode+filter+count on the current stream; returns the device result tensor
+        (int64[4]: total, failed vectors, max status, reserved)."""
+        p = pred if isinstance(pred, N.Pred) else make_pred(self.etype, pred)
+        ws = self.workspace()
+        res = result if result is not None else self.result_buffer()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().cvec_filter_count_dev(C.byref(self.view), C.byref(p), _ptr(res), _ptr(per_vector),
+                                                  _ptr(status), _ptr(masks), _ptr(ws), ws.numel(), _stream_ptr()))
+        return res
+
+    def filter_count(self, pred, per_vector=False, return_status=False, return_masks=False):
+        pv = torch.empty(self.n_vectors, dtype=torch.int64, device=self.device) if per_vector else None
+        st = torch.empty(self.n_vectors, dtype=torch.int32, device=self.device) if return_status else None
+        mk = torch.zeros(self.n_sections * 32, dtype=torch.uint8, device=self.device) if return_masks else None
+        res = self.filter_count_async(pred, pv, st, mk).cpu().numpy()
+        if res[1] and not return_status:
+            raise N.CodingError(int(res[2]), "%d vector(s) failed" % int(res[1]))
+        out = [int(res[0])]
+        if per_vector:
+            out.append(pv.cpu().numpy().view(np.uint64))
+        if return_status:
+            out.append(st.cpu().numpy())
+        if return_masks:
+            out.append(mk.cpu().numpy())
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def decode_async(self, out, add_const=None, status=None, result=None):
+        """Enqueues decode through [AddConstSink →] VecSink into `out` (256 * n_sections elements)."""
+        assert out.numel() >= self.n_sections * FIXED_LEN and out.element_size() == WIDTH[self.etype]
+        chain = make_chain(self.etype, add_const)
+        ws = self.workspace()
+        res = result if result is not None else self.result_buffer()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().cvec_decode_dev(C.byref(self.view), C.byref(chain), _ptr(out), _ptr(res), _ptr(status),
+                                            _ptr(ws), ws.numel(), _stream_ptr()))
+        return res
+
+    def decode(self, add_const=None, return_status=False):
+        """Returns (values, out_off): every vector padded to whole sections, vectors back to back."""
+        out = torch.zeros(self.n_sections * FIXED_LEN, dtype=TORCH_DTYPE[self.etype], device=self.device)
+        st = torch.empty(self.n_vectors, dtype=torch.int32, device=self.device) if return_status else None
+        res = self.decode_async(out, add_const, st).cpu().numpy()
+        if res[1] and not return_status:
+            raise N.CodingError(int(res[2]), "%d vector(s) failed" % int(res[1]))
+        vals = out.cpu().numpy().view(NP_DTYPE[self.etype])
+        off = self.d_sec_base.cpu().numpy().view(np.uint64) * np.uint64(FIXED_LEN)
+        return (vals, off, st.cpu().numpy()) if return_status else (vals, off)
+
+
+def encode_device(etype, d_values, d_elem_off, n_elements_total=None):
+    """Vector*Appender::encode_all for a batch already in HBM.  d_values: 1-D tensor of the element
+    type (int32/int64 carry u32/u64 bits), d_elem_off: int64[n+1].  Returns a DeviceBatch."""
+    etype = etype_of(etype)
+    n = d_elem_off.numel() - 1
+    n_el = int(d_values.numel()) if n_elements_total is None else int(n_elements_total)
+    L = N.lib()
+    cap = L.cvec_max_encoded_bytes(etype, n, n_el)
+    wsb = L.cvec_encode_workspace_bytes(n, n_el)
+    dev = d_values.device
+    d_bytes = torch.empty(((cap + 255) // 256) * 256, dtype=torch.uint8, device=dev)
+    d_byte_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    d_sec_base = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    res = torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        N.check(L.cvec_encode_dev(etype, _ptr(d_values), _ptr(d_elem_off), n, n_el, _ptr(d_bytes), d_bytes.numel(),
+                                  _ptr(d_byte_off), _ptr(d_sec_base), _ptr(res), _ptr(ws), ws.numel(), _stream_ptr()))
+    r = res.cpu().numpy()
+    return DeviceBatch(etype, d_bytes, d_byte_off, d_sec_base, n, int(r[3]), int(r[0]))
+
+
+def encode_batch(etype, values, elem_off):
+    """Host arrays in, host EncodedBatch out (one H2D, encode on the GPU, one D2H)."""
+    etype = etype_of(etype)
+    vals = np.ascontiguousarray(values, dtype=NP_DTYPE[etype])
+    eo = np.ascontiguousarray(elem_off, dtype=np.uint64)
+    if np.any(eo[1:] < eo[:-1]):
+        raise N.CodingError(N.ERR_BAD_ARGUMENT, "elem_off must be non-decreasing")
+    if eo.size > 1 and int((eo[1:] - eo[:-1]).max()) > 0xffffffff:
+        raise N.CodingError(N.INVALID_NUM_ROWS, int((eo[1:] - eo[:-1]).max()), 0xffffffff)
+    n_el = int(eo[-1] - eo[0])
+    signed = vals.view(np.int64 if etype == N.U64 else (np.int32 if etype == N.U32 else np.float32))
+    d_values = torch.from_numpy(signed[int(eo[0]):int(eo[-1])]).cuda() if n_el else \
+        torch.zeros(4, dtype=TORCH_DTYPE[etype], device="cuda")
+    d_eo = torch.from_numpy((eo - eo[0]).view(np.int64)).cuda()
+    return encode_device(etype, d_values, d_eo, n_el).download()

@@ -1,0 +1,550 @@
+// cvec_decode.hip — gfx950 kernels for the read side: section index, fused decode + sink /
+// decode + filter, and the per-vector finalize.
+//
+// Data flow of one operation over a batch (all on one stream):
+//   k_index     one lane per vector walks its section headers (the chain of
+//               FixedSectIterator::next, reference src/section.rs:864-876) and writes one
+//               descriptor per 256-element section slot.
+//   k_sections  one workgroup per tile of TILE consecutive section slots: the tile's bytes are one
+//               contiguous span of the blob, staged once into LDS with 16-byte coalesced loads;
+//               one lane per section walks the 32 octet headers (the chain inside
+//               decode_to_sink, src/section.rs:548-553 / :638-641 / :708-711) and leaves a
+//               32-entry octet table in LDS; then every wave decodes whole sections, 4 elements
+//               per lane, undoes XOR with a wavefront scan and either compares (filter) or stores.
+//   k_finalize  one lane per vector folds its sections' results in order, so a failing section
+//               ends that vector exactly where the reference's iteration would stop.
+#include "cvec_device.hpp"
+
+namespace cvec {
+
+// ------------------------------------------------------------------------------------------------
+// sec_base: number of 256-element sections each vector's header announces.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_header_sections(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ byte_off,
+                                  uint64_t n, uint64_t *__restrict__ nsec) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint64_t start = byte_off[v], len = byte_off[v + 1] - start;
+    uint64_t c = 0;
+    if (len >= HEADER_BYTES) {
+        uint32_t ne = *(const u32u *)(bytes + start + 8); // FixedSectStats.num_elements, src/vector.rs:165
+        c = ((uint64_t)ne + FIXED_LEN - 1) / FIXED_LEN;
+    }
+    nsec[v] = c;
+}
+
+// Exclusive scan of u64 in three steps (block sums, scan of block sums, add).  SCAN_BLOCK elements
+// per workgroup; the middle step is a single workgroup looping over the block sums.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline uint64_t wave_incl_scan_u64(uint64_t x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+// Inclusive scan across a 256-thread workgroup; returns this thread's inclusive value and the
+// workgroup total.
+__device__ inline uint64_t block_incl_scan_u64(uint64_t x, uint64_t *total, uint64_t *s_wave /*[4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = wave_incl_scan_u64(x);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t add = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        uint64_t s = s_wave[w];
+        if (w < wave) add += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return incl + add;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint64_t *__restrict__ in, uint64_t n,
+                                                                  uint64_t *__restrict__ block_sums) {
+    __shared__ uint64_t s_wave[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) sum += in[base + i];
+    uint64_t total;
+    block_incl_scan_u64(sum, &total, s_wave);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_of_sums(uint64_t *__restrict__ block_sums, uint64_t nblocks,
+                                                               uint64_t *__restrict__ grand_total) {
+    __shared__ uint64_t s_wave[4];
+    uint64_t carry = 0;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += SCAN_THREADS) {
+        uint64_t i = b0 + threadIdx.x;
+        uint64_t x = i < nblocks ? block_sums[i] : 0;
+        uint64_t total;
+        uint64_t incl = block_incl_scan_u64(x, &total, s_wave);
+        if (i < nblocks) block_sums[i] = carry + incl - x; // exclusive
+        carry += total;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+
+// out[i] = exclusive prefix of in[0..i); out[n] = grand total.  `in` and `out` may alias.
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint64_t *in, uint64_t n,
+                                                             const uint64_t *__restrict__ block_excl,
+                                                             const uint64_t *__restrict__ grand_total, uint64_t *out) {
+    __shared__ uint64_t s_wave[4];
+    uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t x[SCAN_ITEMS];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        x[i] = base + i < n ? in[base + i] : 0;
+        sum += x[i];
+    }
+    uint64_t total;
+    uint64_t incl = block_incl_scan_u64(sum, &total, s_wave);
+    uint64_t run = block_excl[blockIdx.x] + incl - sum;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += x[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = *grand_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_index: VectorReader::try_new (src/vector.rs:404-414) + the FixedSectIterator chain.
+// ------------------------------------------------------------------------------------------------
+template <int ETYPE>
+__global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes,
+                                               const uint64_t *__restrict__ byte_off,
+                                               const uint64_t *__restrict__ sec_base, uint64_t n,
+                                               uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
+                                               uint64_t *__restrict__ result) {
+    constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < CVEC_RESULT_WORDS) result[v] = 0; // k_finalize accumulates into it two launches later
+    if (v >= n) return;
+    const uint64_t start = byte_off[v], L = byte_off[v + 1] - start;
+    const uint64_t slot0 = sec_base[v], nslots = sec_base[v + 1] - slot0;
+    const uint8_t *p = bytes + start;
+    int st = CVEC_OK;
+    // scroll pread error mapping of try_new, then the reader's own checks
+    if (L == 0) st = CVEC_BAD_OFFSET;
+    else if (L < 4) st = CVEC_NOT_ENOUGH_SPACE;
+    else if (L <= 5) st = CVEC_BAD_OFFSET;
+    else {
+        uint64_t from_header = *(const u32u *)p;
+        uint32_t subtype = p[5];
+        if (L < from_header + 4) st = CVEC_INPUT_TOO_SHORT;
+        else if (subtype != (uint32_t)ETYPE) st = CVEC_WRONG_VECTOR_TYPE;
+        else if (L < HEADER_BYTES) st = CVEC_INPUT_TOO_SHORT;
+    }
+    uint64_t k = 0, pos = HEADER_BYTES;
+    if (st == CVEC_OK) {
+        while (pos < L) { // sections are walked to the end of the slice (src/vector.rs:443)
+            const uint64_t rem = L - pos;
+            const uint32_t b0 = p[pos];
+            uint64_t nb = 0;
+            int e = CVEC_OK;
+            if (b0 == K_NULL) {
+                nb = 1;
+            } else if (b0 == K_CONST) {
+                if (rem < 1 + (uint64_t)W) e = CVEC_INPUT_TOO_SHORT;
+                nb = 1 + W;
+            } else if (b0 == K_NP || b0 == K_DELTA || b0 == K_XOR) {
+                if (rem <= 1) e = CVEC_BAD_OFFSET;
+                else if (rem < 3) e = CVEC_NOT_ENOUGH_SPACE;
+                else {
+                    uint32_t n16 = *(const u16u *)(p + pos + 1);
+                    nb = b0 == K_NP ? (uint64_t)n16 + 3 : (b0 == K_DELTA ? (uint64_t)n16 + DELTA_HDR : n16);
+                    if (nb > rem) e = CVEC_SCROLL_ERR;
+                    else if (nb < 3) e = CVEC_INVALID_FORMAT;
+                }
+            } else {
+                e = CVEC_INVALID_SECTION_TYPE;
+            }
+            if (e) { st = e; break; }
+            if (k >= nslots) { st = CVEC_ERR_SECTION_COUNT; break; }
+            const bool legal = ETYPE == CVEC_F32 ? (b0 == K_NULL || b0 == K_CONST || b0 == K_XOR) : (b0 != K_XOR);
+            desc[slot0 + k] = desc_pack(start + pos, (uint32_t)nb, legal ? b0 : K_ILLEGAL);
+            pos += nb;
+            k++;
+        }
+        if (st == CVEC_OK && k != nslots) st = CVEC_ERR_SECTION_COUNT;
+    }
+    const uint64_t fill_off = start + (pos < L ? pos : L);
+    for (; k < nslots; k++) desc[slot0 + k] = desc_pack(fill_off, 0, K_SKIP);
+    vstatus[v] = st;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sections
+// ------------------------------------------------------------------------------------------------
+constexpr int TILE = 32;            // section slots per workgroup
+constexpr int SEC_THREADS = 256;    // 4 waves
+constexpr int OCT_STRIDE = 33;      // dwords per section in the octet table (33: bank-conflict-free)
+// LDS: 35 KiB of staged bytes covers 32 worst-case u32/f32 sections (1100 B) + the vector headers
+// between them; with the tables a workgroup stays under 40 KiB, so four workgroups share a CU's
+// 160 KiB.
+constexpr uint32_t LDS_DATA_BYTES = 35840;
+constexpr uint32_t LDS_DATA_PAD = 32;
+
+enum { MODE_FILTER = 0, MODE_DECODE = 1 };
+
+struct SecShared {
+    __attribute__((aligned(16))) uint8_t data[LDS_DATA_BYTES + LDS_DATA_PAD];
+    uint32_t octab[TILE * OCT_STRIDE];
+    uint64_t off[TILE];
+    uint32_t len[TILE];  // bytes of the section the walk may touch (clipped to SectLimits)
+    uint32_t kind[TILE];
+    uint32_t err[TILE];
+    uint32_t rel[TILE];  // section start relative to the staged span
+    int group_end;
+};
+
+// One octet element: field `idx` (of width 4n bits) of the little-endian bitstream that follows the
+// two octet header bytes, shifted left by the trailing-zero nibbles; zero lanes give 0.  This is the
+// plain bitstream rule of the format (reference src/nibblepacking.rs:436-470,
+// src/nibblepack_simd.rs:571-585).
+template <int W>
+__device__ inline typename Elem<W>::U extract_elem(const uint8_t *sec, uint32_t d, uint32_t j, uint32_t jmask) {
+    const uint32_t rel = d & 0xffffu, mask = (d >> 16) & 0xffu, nw = d >> 24;
+    const uint32_t n4 = ((nw >> 4) + 1) << 2, tz = (nw & 15) << 2;
+    const uint32_t idx = __popc(mask & jmask);
+    const uint32_t bitpos = idx * n4;
+    const uint8_t *a = sec + rel + 2 + (bitpos >> 3);
+    const uint32_t sh = bitpos & 7; // 0 or 4
+    if constexpr (W == 4) {
+        uint64_t w = *(const u64u *)a;
+        uint32_t x = (uint32_t)(w >> sh);
+        x &= 0xffffffffu >> (32 - n4);
+        x = (uint32_t)((uint64_t)x << tz); // a shift count >= 32 yields 0, as the AVX2 lane shift does
+        return ((mask >> j) & 1) ? x : 0u;
+    } else {
+        uint64_t w0 = *(const u64u *)a;
+        uint64_t w1 = a[8];
+        uint64_t x = sh ? ((w0 >> 4) | (w1 << 60)) : w0;
+        x &= ~0ull >> (64 - n4);
+        x <<= tz;
+        return ((mask >> j) & 1) ? x : 0ull;
+    }
+}
+
+template <int W> __device__ inline typename Elem<W>::U shfl_up_t(typename Elem<W>::U x, int d) {
+    return __shfl_up(x, d, 64);
+}
+
+template <int ETYPE>
+__device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CVEC_U64 ? 8 : 4)>::U x) {
+    bool m = false;
+    if constexpr (ETYPE == CVEC_F32) {
+        const float f = __uint_as_float((uint32_t)x);
+        for (uint32_t p = 0; p < pa.count; p++) m |= (f == __uint_as_float((uint32_t)pa.v[p])); // IEEE ==
+    } else if constexpr (ETYPE == CVEC_U32) {
+        for (uint32_t p = 0; p < pa.count; p++) m |= ((uint32_t)x == (uint32_t)pa.v[p]);
+    } else {
+        for (uint32_t p = 0; p < pa.count; p++) m |= (x == pa.v[p]);
+    }
+    return m;
+}
+
+template <int ETYPE, int MODE>
+__global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restrict__ bytes,
+                                                          const uint64_t *__restrict__ desc, uint64_t n_sections,
+                                                          PredArgs pa, SinkArgs sa, uint32_t *__restrict__ sec_res,
+                                                          uint8_t *__restrict__ masks, void *__restrict__ out_) {
+    constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
+    using U = typename Elem<W>::U;
+    __shared__ SecShared sm;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t s0 = (uint64_t)blockIdx.x * TILE;
+    const int nsec = (int)((n_sections - s0) < (uint64_t)TILE ? (n_sections - s0) : (uint64_t)TILE);
+
+    if (tid < TILE) {
+        uint64_t d = tid < nsec ? desc[s0 + tid] : desc_pack(0, 0, K_SKIP);
+        uint32_t len = desc_len(d);
+        sm.off[tid] = desc_off(d);
+        sm.len[tid] = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
+        sm.kind[tid] = desc_kind(d);
+        sm.err[tid] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t g = lane >> 3, j = lane & 7, jmask = (1u << j) - 1u;
+    U *out = (U *)out_;
+
+    int i0 = 0;
+    while (i0 < nsec) {
+        // ---- group = longest run of sections from i0 whose bytes fit the staging buffer ----------
+        const uint64_t gbase = sm.off[i0] & ~15ull;
+        if (wave == 0) {
+            bool fits = lane < i0;
+            if (lane >= i0 && lane < nsec) fits = (sm.off[lane] + sm.len[lane] - gbase) <= (uint64_t)LDS_DATA_BYTES;
+            unsigned long long m = __ballot(fits);
+            int i1 = m == ~0ull ? 64 : __builtin_ctzll(~m);
+            if (lane == 0) sm.group_end = i1 < nsec ? i1 : nsec;
+        }
+        __syncthreads();
+        const int i1 = sm.group_end;
+        // ---- stage [gbase, end of section i1-1) with coalesced 16-byte loads -------------------------
+        {
+            const uint32_t span = (uint32_t)(sm.off[i1 - 1] + sm.len[i1 - 1] - gbase);
+            const uint32_t nchunks = (span + 15) >> 4;
+            const uint4 *src = (const uint4 *)(bytes + gbase);
+            uint4 *dst = (uint4 *)sm.data;
+            for (uint32_t c = tid; c < nchunks; c += SEC_THREADS) dst[c] = src[c];
+            if (tid >= i0 && tid < i1) sm.rel[tid] = (uint32_t)(sm.off[tid] - gbase);
+        }
+        __syncthreads();
+        // ---- octet walk: one lane per section ----------------------------------------------------------
+        if (tid >= i0 && tid < i1) {
+            const uint32_t kind = sm.kind[tid];
+            if (kind == K_NP || kind == K_DELTA || kind == K_XOR) {
+                const uint32_t rel = sm.rel[tid];
+                const int end = (int)(rel + sm.len[tid]);
+                int p = (int)rel + (kind == K_DELTA ? DELTA_HDR : 3);
+                uint32_t err = 0;
+                for (int k = 0; k < FIXED_LEN / 8; k++) {
+                    const int rem = end - p;
+                    if (rem <= 0) { err = CVEC_NOT_ENOUGH_SPACE; break; }
+                    const uint32_t h = *(const u16u *)(sm.data + p);
+                    const uint32_t mask = h & 0xffu;
+                    uint32_t entry = (uint32_t)(p - (int)rel);
+                    int size = 1;
+                    if (mask) {
+                        const uint32_t nw = h >> 8;
+                        const uint32_t n = (nw >> 4) + 1;
+                        size = 2 + (int)((n * __popc(mask) + 1) >> 1);
+                        if constexpr (W == 4) {
+                            if (rem < 3) err = CVEC_NOT_ENOUGH_SPACE;
+                            else if (n > 8) err = CVEC_INVALID_FORMAT;
+                            else if (size > rem) err = CVEC_NOT_ENOUGH_SPACE;
+                        } else {
+                            if (rem < 2 || size > rem) err = CVEC_NOT_ENOUGH_SPACE;
+                        }
+                        if (err) break;
+                        entry |= h << 16;
+                    }
+                    sm.octab[tid * OCT_STRIDE + k] = entry;
+                    p += size;
+                }
+                sm.err[tid] = err;
+            }
+        }
+        __syncthreads();
+        // ---- decode: each wave takes whole sections; lane (g, j) owns lane j of octets 4g..4g+3 ------
+        for (int t = i0 + wave; t < i1; t += SEC_THREADS / 64) {
+            const uint32_t kind = __builtin_amdgcn_readfirstlane(sm.kind[t]);
+            const uint32_t err = __builtin_amdgcn_readfirstlane(sm.err[t]);
+            const uint64_t slot = s0 + t;
+            uint32_t res;
+            if (kind == K_SKIP) {
+                res = res_pack(0, 0);
+            } else if (kind == K_ILLEGAL) {
+                res = res_pack(0, CVEC_INVALID_FORMAT);
+            } else if (err) {
+                res = res_pack(0, err);
+            } else {
+                const uint8_t *sec = sm.data + __builtin_amdgcn_readfirstlane(sm.rel[t]);
+                U x[4];
+                bool zeroes = false; // the section reaches the sink through process_zeroes()
+                if (kind == K_NULL) {
+                    x[0] = x[1] = x[2] = x[3] = 0;
+                    zeroes = true;
+                } else if (kind == K_CONST) {
+                    U v;
+                    if constexpr (W == 4) v = *(const u32u *)(sec + 1); else v = *(const u64u *)(sec + 1);
+                    x[0] = x[1] = x[2] = x[3] = v;
+                } else {
+                    const uint32_t *tab = sm.octab + t * OCT_STRIDE + 4 * g;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) x[i] = extract_elem<W>(sec, tab[i], j, jmask);
+                    if (ETYPE == CVEC_F32) {
+                        // XorSink: out[k] = out[k-1] ^ x[k] per lane j, state zero at the section start
+                        // (src/sink.rs:271-275, src/section.rs:707): serial over the lane's 4 octets,
+                        // then an exclusive scan over the 8 octet groups (lane strides 8, 16, 32).
+                        x[1] ^= x[0]; x[2] ^= x[1]; x[3] ^= x[2];
+                        U tot = x[3];
+                        U y = shfl_up_t<W>(tot, 8);  if (g >= 1) tot ^= y;
+                        y = shfl_up_t<W>(tot, 16);   if (g >= 2) tot ^= y;
+                        y = shfl_up_t<W>(tot, 32);   if (g >= 4) tot ^= y;
+                        U excl = shfl_up_t<W>(tot, 8);
+                        if (g == 0) excl = 0;
+                        x[0] ^= excl; x[1] ^= excl; x[2] ^= excl; x[3] ^= excl;
+                    } else if (kind == K_DELTA) {
+                        // AddConstSink(base) around the octet decode (src/section.rs:636-641), wrapping
+                        U base;
+                        if constexpr (W == 4) base = *(const u32u *)(sec + 4); else base = *(const u64u *)(sec + 4);
+                        x[0] += base; x[1] += base; x[2] += base; x[3] += base;
+                    }
+                }
+                if constexpr (MODE == MODE_FILTER) {
+                    uint32_t cnt = 0;
+                    if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
+                        cnt = pa.match_zero ? FIXED_LEN : 0;
+                        if (masks && lane < 8) ((uint32_t *)(masks + slot * 32))[lane] = pa.match_zero ? ~0u : 0u;
+                    } else {
+                        uint32_t mword = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            unsigned long long b = __ballot(pred_match<ETYPE>(pa, x[i]));
+                            cnt += __popcll(b);
+                            mword |= (uint32_t)((b >> (8 * g)) & 0xffu) << (8 * i);
+                        }
+                        if (masks && j == 0) ((uint32_t *)(masks + slot * 32))[g] = mword;
+                    }
+                    res = res_pack(cnt, 0);
+                } else {
+                    if (sa.add_const) {
+                        // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards
+                        // the base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
+                        if constexpr (ETYPE == CVEC_F32) {
+                            const float b = __uint_as_float((uint32_t)sa.base);
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                x[i] = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x[i]) + b);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) x[i] += (U)sa.base;
+                        }
+                    }
+                    U *o = out + slot * FIXED_LEN + 32 * g + j;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o[8 * i] = x[i];
+                    res = res_pack(FIXED_LEN, 0);
+                }
+            }
+            if (lane == 0) sec_res[slot] = res;
+        }
+        __syncthreads();
+        i0 = i1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_finalize: fold the per-section results of each vector in order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ sec_base, uint64_t n,
+                                                  const uint32_t *__restrict__ sec_res,
+                                                  const int32_t *__restrict__ vstatus,
+                                                  uint64_t *__restrict__ per_vec, int32_t *__restrict__ status_out,
+                                                  uint64_t *__restrict__ result) {
+    __shared__ uint64_t s_cnt[4];
+    __shared__ uint32_t s_nerr[4], s_max[4];
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t cnt = 0;
+    uint32_t st = 0;
+    if (v < n) {
+        const uint64_t a = sec_base[v], b = sec_base[v + 1];
+        for (uint64_t s = a; s < b; s++) {
+            const uint32_t r = sec_res[s];
+            if (r >> 16) { st = r >> 16; break; } // the reference's iteration stops at the first failing section
+            cnt += r & 0xffffu;
+        }
+        if (!st) st = (uint32_t)vstatus[v];
+        if (per_vec) per_vec[v] = cnt;
+        if (status_out) status_out[v] = (int32_t)st;
+    }
+    uint32_t nerr = st ? 1 : 0, mx = st;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_down(cnt, d, 64);
+        nerr += __shfl_down(nerr, d, 64);
+        uint32_t o = __shfl_down(mx, d, 64);
+        mx = o > mx ? o : mx;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_cnt[wave] = cnt; s_nerr[wave] = nerr; s_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        uint32_t e = s_nerr[0] + s_nerr[1] + s_nerr[2] + s_nerr[3];
+        uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (c) atomicAdd((unsigned long long *)&result[0], (unsigned long long)c);
+        if (e) {
+            atomicAdd((unsigned long long *)&result[1], (unsigned long long)e);
+            atomicMax((unsigned long long *)&result[2], (unsigned long long)m);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_sec_base(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n, uint64_t *d_sec_base,
+                           uint64_t *d_scratch /* ceil(n/SCAN_BLOCK)+1 u64 */, hipStream_t stream) {
+    if (n == 0) return hipMemsetAsync(d_sec_base, 0, sizeof(uint64_t), stream);
+    const uint32_t nblk = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    k_header_sections<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(d_bytes, d_byte_off, n, d_sec_base);
+    k_scan_block_sums<<<nblk, SCAN_THREADS, 0, stream>>>(d_sec_base, n, d_scratch);
+    k_scan_of_sums<<<1, SCAN_THREADS, 0, stream>>>(d_scratch, nblk, d_scratch + nblk);
+    k_scan_apply<<<nblk, SCAN_THREADS, 0, stream>>>(d_sec_base, n, d_scratch, d_scratch + nblk, d_sec_base);
+    return hipGetLastError();
+}
+
+uint64_t scan_scratch_words(uint64_t n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK + 2; }
+
+hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_out /* n+1 */, uint64_t *d_scratch,
+                                 hipStream_t stream) {
+    if (n == 0) return hipMemsetAsync(d_out, 0, sizeof(uint64_t), stream);
+    const uint32_t nblk = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    k_scan_block_sums<<<nblk, SCAN_THREADS, 0, stream>>>(d_in, n, d_scratch);
+    k_scan_of_sums<<<1, SCAN_THREADS, 0, stream>>>(d_scratch, nblk, d_scratch + nblk);
+    k_scan_apply<<<nblk, SCAN_THREADS, 0, stream>>>(d_in, n, d_scratch, d_scratch + nblk, d_out);
+    return hipGetLastError();
+}
+
+template <int ETYPE>
+static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
+                          uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
+                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
+                          hipStream_t stream) {
+    const uint64_t n = b.n_vectors, ns = b.n_sections;
+    k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
+                                                                                 n, desc, vstatus, d_result);
+    if (ns > 0) {
+        const uint32_t ntiles = (uint32_t)((ns + TILE - 1) / TILE);
+        if (mode == MODE_FILTER)
+            k_sections<ETYPE, MODE_FILTER><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res,
+                                                                               d_masks, nullptr);
+        else
+            k_sections<ETYPE, MODE_DECODE><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res,
+                                                                               nullptr, d_out);
+    }
+    if (n > 0)
+        k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,
+                                                                    d_status, d_result);
+}
+
+hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
+                       uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
+                       int32_t *d_status, uint8_t *d_masks, void *d_out, hipStream_t stream) {
+    switch (b.etype) {
+    case CVEC_U32:
+        launch_read_t<CVEC_U32>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
+                                d_out, stream);
+        break;
+    case CVEC_U64:
+        launch_read_t<CVEC_U64>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
+                                d_out, stream);
+        break;
+    case CVEC_F32:
+        launch_read_t<CVEC_F32>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
+                                d_out, stream);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace cvec

@@ -1,0 +1,59 @@
+// cvec_device.hpp — shared device-side definitions for the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cvec.h"
+
+namespace cvec {
+
+constexpr int FIXED_LEN = 256;   // elements per section (reference src/section.rs:184)
+constexpr int HEADER_BYTES = 16; // vector header (reference src/vector.rs:110)
+constexpr int DELTA_HDR = 12;    // Delta section header (reference src/section.rs:607)
+
+// Section kinds as stored in a section descriptor: the reference's type bytes
+// (src/section.rs:32-38) plus two internal markers.
+constexpr uint32_t K_NULL = 0, K_NP = 1, K_DELTA = 3, K_CONST = 5, K_XOR = 6;
+constexpr uint32_t K_ILLEGAL = 0x7e; // well-formed section of a kind the element type cannot hold
+constexpr uint32_t K_SKIP = 0x7f;    // slot after a parse error / beyond the sections found
+
+// Section descriptor: byte offset in the blob (40 bits) | num_bytes() (17 bits) | kind (7 bits).
+__host__ __device__ inline uint64_t desc_pack(uint64_t off, uint32_t len, uint32_t kind) {
+    return off | ((uint64_t)len << 40) | ((uint64_t)kind << 57);
+}
+__host__ __device__ inline uint64_t desc_off(uint64_t d) { return d & ((1ull << 40) - 1); }
+__host__ __device__ inline uint32_t desc_len(uint64_t d) { return (uint32_t)(d >> 40) & 0x1ffffu; }
+__host__ __device__ inline uint32_t desc_kind(uint64_t d) { return (uint32_t)(d >> 57); }
+
+// Largest span of a section the octet walk can touch: header + 32 octets of 2 + 8*W/2... bytes.
+template <int W> struct SectLimits;
+template <> struct SectLimits<4> { static constexpr uint32_t MAX_BYTES = DELTA_HDR + 32 * 34; };
+template <> struct SectLimits<8> { static constexpr uint32_t MAX_BYTES = DELTA_HDR + 32 * 66; };
+
+// Unaligned little-endian loads.  gfx950 runs with unaligned global/LDS access enabled, so these
+// compile to single global_load / ds_read instructions.
+typedef uint16_t __attribute__((aligned(1))) u16u;
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint64_t __attribute__((aligned(1))) u64u;
+
+template <int W> struct Elem;
+template <> struct Elem<4> { using U = uint32_t; };
+template <> struct Elem<8> { using U = uint64_t; };
+
+// Per-section result word: low 16 bits = count (matches / elements stored), high 16 = status.
+__device__ inline uint32_t res_pack(uint32_t count, uint32_t err) { return count | (err << 16); }
+
+// Predicate / sink arguments passed to kernels by value.
+struct PredArgs {
+    uint32_t count;
+    uint32_t match_zero;
+    uint64_t v[CVEC_MAX_PRED_VALUES];
+};
+struct SinkArgs {
+    uint32_t add_const;
+    uint32_t _pad;
+    uint64_t base;
+};
+
+} // namespace cvec

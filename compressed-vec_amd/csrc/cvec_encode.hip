@@ -1,0 +1,422 @@
+// cvec_encode.hip — gfx950 kernels for the write side: Vector{U32,U64,F32Xor}Appender::encode_all
+// (reference src/vector.rs:238-246) for a batch of vectors.
+//
+// One wavefront encodes one 256-element section.  Lane L holds elements L, L+64, L+128, L+192, so
+// register i of lanes 8g..8g+7 is octet 8i+g and the octet-level quantities of NibblePack
+// (reference src/nibblepacking.rs:108-153) are 8-lane group operations:
+//   nonzero bitmask      = one byte of a wave ballot
+//   nibble word          = clz/ctz of the OR over the 8 lanes (xor-butterfly over lanes 1, 2, 4)
+//   octet byte offsets   = exclusive scan of the 32 octet sizes (lane strides 8, 16, 32 + carry)
+//   bitstream            = every nonzero lane ORs its field into a zeroed LDS image of the section
+// Because a section's byte offset depends on every section before it, the work is two passes over
+// the values: sizes → exclusive scan of section sizes → emit.
+#include "cvec_device.hpp"
+
+namespace cvec {
+
+hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_scratch,
+                                 hipStream_t stream);
+uint64_t scan_scratch_words(uint64_t n);
+
+constexpr int ENC_THREADS = 256; // 4 waves = 4 sections per workgroup
+
+template <int ETYPE> struct EncT {
+    static constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
+    using U = typename Elem<W>::U;
+};
+
+template <class U> __device__ inline U wave_min_u(U x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { U y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
+    return x;
+}
+template <class U> __device__ inline U wave_max_u(U x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { U y = __shfl_xor(x, d, 64); x = y > x ? y : x; }
+    return x;
+}
+__device__ inline float wave_min_f(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { float y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
+    return x;
+}
+__device__ inline float wave_max_f(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { float y = __shfl_xor(x, d, 64); x = y > x ? y : x; }
+    return x;
+}
+__device__ inline uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+__device__ inline uint32_t bitlen_u(uint32_t x) { return x ? 32u - (uint32_t)__clz(x) : 0u; }
+__device__ inline uint32_t bitlen_u(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }
+
+// Section plan, identical in every lane of the wave.
+template <class U> struct SecPlan {
+    uint32_t kind;
+    U minv;      // Delta base
+    U maxv;
+    U first;     // values[0] (Const payload)
+};
+
+// SectionWriterStats::from_vect + writer choice (reference src/section.rs:473-480, :719-732,
+// :823-845).  For f32 the fold keeps the first minimum / last maximum and treats an unordered
+// compare as Equal: min is NaN iff values[0] is NaN (NaNs after it are skipped); max restarts after
+// every NaN, so it is NaN iff the last value is, else the maximum of the values after the last NaN.
+template <int ETYPE>
+__device__ inline SecPlan<typename EncT<ETYPE>::U> plan_section(const typename EncT<ETYPE>::U x[4], int lane) {
+    using U = typename EncT<ETYPE>::U;
+    SecPlan<U> p;
+    p.first = __shfl(x[0], 0, 64);
+    if constexpr (ETYPE == CVEC_F32) {
+        float f[4];
+        unsigned long long nanb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { f[i] = __uint_as_float(x[i]); nanb[i] = __ballot(f[i] != f[i]); }
+        int q = -1; // index of the last NaN
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (nanb[i]) q = 64 * i + 63 - __builtin_clzll(nanb[i]);
+        const float inf = __builtin_inff();
+        float mn = inf, mx = -inf;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool isn = f[i] != f[i];
+            mn = (!isn && f[i] < mn) ? f[i] : mn;
+            mx = (64 * i + lane > q && f[i] > mx) ? f[i] : mx;
+        }
+        mn = wave_min_f(mn);
+        mx = wave_max_f(mx);
+        const float first = __uint_as_float(p.first);
+        if (first != first) mn = first;                  // min fold is stuck on a leading NaN
+        if (q == FIXED_LEN - 1) mx = __builtin_nanf(""); // max fold ends on a trailing NaN
+        p.minv = __float_as_uint(mn);
+        p.maxv = __float_as_uint(mx);
+        if (mn == mx) p.kind = (mn == 0.0f) ? K_NULL : K_CONST;
+        else p.kind = K_XOR;
+    } else {
+        U mn = x[0], mx = x[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++) { mn = x[i] < mn ? x[i] : mn; mx = x[i] > mx ? x[i] : mx; }
+        mn = wave_min_u<U>(mn);
+        mx = wave_max_u<U>(mx);
+        p.minv = mn;
+        p.maxv = mx;
+        if (mn == mx) p.kind = (mn == 0) ? K_NULL : K_CONST;
+        else {
+            const uint32_t reg = (bitlen_u(mx) + 3) / 4, rng = (bitlen_u((U)(mx - mn)) + 3) / 4;
+            p.kind = rng < reg ? K_DELTA : K_NP;
+        }
+    }
+    return p;
+}
+
+// What NibblePack sees: XOR against the previous octet (f32, reference src/section.rs:738-743),
+// value - min (Delta, :656) or the value itself.
+template <int ETYPE>
+__device__ inline void transform_section(typename EncT<ETYPE>::U x[4], uint32_t kind,
+                                         typename EncT<ETYPE>::U minv, int lane) {
+    using U = typename EncT<ETYPE>::U;
+    if constexpr (ETYPE == CVEC_F32) {
+        U prev[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            U up = __shfl_up(x[i], 8, 64);                                   // element e-8, lanes >= 8
+            U wrap = i > 0 ? __shfl(x[i > 0 ? i - 1 : 0], (lane + 56) & 63, 64) : (U)0; // lanes < 8
+            prev[i] = lane >= 8 ? up : wrap;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] ^= prev[i];
+    } else {
+        if (kind == K_DELTA) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] -= minv;
+        }
+    }
+}
+
+struct OctInfo {
+    uint32_t mask;  // nonzero bitmask of this lane's octet
+    uint32_t n, t;  // nibbles kept, trailing zero nibbles dropped
+    uint32_t size;  // octet bytes
+};
+
+template <class U> __device__ inline OctInfo octet_info(U y, int lane) {
+    OctInfo o;
+    const unsigned long long b = __ballot(y != 0);
+    o.mask = (uint32_t)(b >> (lane & 56)) & 0xffu;
+    U r = y;
+    r |= __shfl_xor(r, 1, 64);
+    r |= __shfl_xor(r, 2, 64);
+    r |= __shfl_xor(r, 4, 64);
+    if (o.mask) {
+        uint32_t lz, tz;
+        if constexpr (sizeof(U) == 8) { lz = (uint32_t)__clzll((long long)r); tz = (uint32_t)__ffsll((long long)r) - 1; }
+        else { lz = 32u + (uint32_t)__clz((int)r); tz = (uint32_t)__ffs((int)r) - 1; }
+        o.t = tz >> 2;
+        o.n = 16 - (lz >> 2) - o.t;
+        o.size = 2 + ((o.n * __popc(o.mask) + 1) >> 1);
+    } else {
+        o.t = 0; o.n = 0; o.size = 1;
+    }
+    return o;
+}
+
+template <int ETYPE>
+__device__ inline void load_section(const typename EncT<ETYPE>::U *__restrict__ values, uint64_t e0, uint32_t valid,
+                                    int lane, typename EncT<ETYPE>::U x[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t e = 64 * i + lane;
+        x[i] = e < valid ? values[e0 + e] : 0; // finish() pads the last section with zeros (src/vector.rs:352-355)
+    }
+}
+
+// ---- vector → section bookkeeping -------------------------------------------------------------
+__global__ void k_enc_nsec(const uint64_t *__restrict__ elem_off, uint64_t n, uint64_t *__restrict__ nsec) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    nsec[v] = (elem_off[v + 1] - elem_off[v] + FIXED_LEN - 1) / FIXED_LEN;
+}
+
+__global__ void k_enc_map(const uint64_t *__restrict__ sec_base, uint64_t n, uint32_t *__restrict__ sec_vec) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    for (uint64_t s = sec_base[v]; s < sec_base[v + 1]; s++) sec_vec[s] = (uint32_t)v;
+}
+
+// ---- pass A: section sizes ------------------------------------------------------------------------
+template <int ETYPE>
+__global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const typename EncT<ETYPE>::U *__restrict__ values,
+                                                            const uint64_t *__restrict__ elem_off,
+                                                            const uint64_t *__restrict__ sec_base, uint64_t n_vectors,
+                                                            const uint32_t *__restrict__ sec_vec, uint64_t max_slots,
+                                                            uint64_t *__restrict__ sec_size) {
+    using U = typename EncT<ETYPE>::U;
+    constexpr int W = EncT<ETYPE>::W;
+    const int lane = threadIdx.x & 63;
+    const uint64_t slot = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + (threadIdx.x >> 6);
+    if (slot >= max_slots) return;
+    const uint64_t n_slots = sec_base[n_vectors];
+    if (slot >= n_slots) { if (lane == 0) sec_size[slot] = 0; return; }
+    const uint32_t v = sec_vec[slot];
+    const uint64_t k = slot - sec_base[v];
+    const uint64_t e0 = elem_off[v] + k * FIXED_LEN, eend = elem_off[v + 1];
+    const uint32_t valid = (uint32_t)((eend - e0) < FIXED_LEN ? (eend - e0) : FIXED_LEN);
+    U x[4];
+    load_section<ETYPE>(values, e0, valid, lane, x);
+    const SecPlan<U> p = plan_section<ETYPE>(x, lane);
+    uint32_t size;
+    if (p.kind == K_NULL) size = 1;
+    else if (p.kind == K_CONST) size = 1 + W;
+    else {
+        transform_section<ETYPE>(x, p.kind, p.minv, lane);
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const OctInfo o = octet_info<U>(x[i], lane);
+            s += (lane & 7) == 0 ? o.size : 0;
+        }
+        size = (p.kind == K_DELTA ? DELTA_HDR : 3) + wave_sum_u32(s);
+    }
+    if (lane == 0) sec_size[slot] = size;
+}
+
+// ---- headers + byte_off -----------------------------------------------------------------------------
+__global__ void k_enc_headers(int32_t etype, const uint64_t *__restrict__ elem_off, const uint64_t *__restrict__ sec_base,
+                              const uint64_t *__restrict__ sec_scan, uint64_t n, uint8_t *__restrict__ bytes,
+                              uint64_t *__restrict__ byte_off, uint64_t *__restrict__ result) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    // vector v starts after v headers and all sections of the vectors before it
+    const uint64_t start = HEADER_BYTES * v + sec_scan[sec_base[v]];
+    byte_off[v] = start;
+    if (v == n) {
+        result[0] = start; result[1] = 0; result[2] = 0; result[3] = sec_base[n];
+        return;
+    }
+    const uint64_t end = HEADER_BYTES * (v + 1) + sec_scan[sec_base[v + 1]];
+    const uint32_t num_bytes = (uint32_t)(end - start - 4);            // BinaryVector.num_bytes (src/vector.rs:54, :139)
+    const uint32_t num_elements = (uint32_t)(elem_off[v + 1] - elem_off[v]);
+    uint8_t *h = bytes + start;
+    *(u32u *)(h + 0) = num_bytes;
+    h[4] = 0x10;                                                        // VectorType::FixedSection256
+    h[5] = (uint8_t)etype;                                              // VectorSubType
+    h[6] = 0; h[7] = 0;
+    *(u32u *)(h + 8) = num_elements;                                    // FixedSectStats (src/vector.rs:163-186)
+    h[12] = 0; h[13] = 0;                                               // num_null_sections: 0 for encode_all
+    h[14] = 0; h[15] = 0;
+}
+
+// ---- pass B: emit ---------------------------------------------------------------------------------------
+template <int W> struct EncBuf { static constexpr int DWORDS = (SectLimits<W>::MAX_BYTES + 3) / 4 + 3; };
+
+template <int ETYPE>
+__global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ETYPE>::U *__restrict__ values,
+                                                           const uint64_t *__restrict__ elem_off,
+                                                           const uint64_t *__restrict__ sec_base, uint64_t n_vectors,
+                                                           const uint32_t *__restrict__ sec_vec, uint64_t max_slots,
+                                                           const uint64_t *__restrict__ sec_scan,
+                                                           uint8_t *__restrict__ bytes) {
+    using U = typename EncT<ETYPE>::U;
+    constexpr int W = EncT<ETYPE>::W;
+    __shared__ uint32_t s_buf[ENC_THREADS / 64][EncBuf<W>::DWORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t slot = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + wave;
+    if (slot >= max_slots) return;
+    if (slot >= sec_base[n_vectors]) return;
+    const uint32_t v = sec_vec[slot];
+    const uint64_t k = slot - sec_base[v];
+    const uint64_t e0 = elem_off[v] + k * FIXED_LEN, eend = elem_off[v + 1];
+    const uint32_t valid = (uint32_t)((eend - e0) < FIXED_LEN ? (eend - e0) : FIXED_LEN);
+    const uint64_t dst_off = HEADER_BYTES * ((uint64_t)v + 1) + sec_scan[slot];
+    const uint32_t size = (uint32_t)(sec_scan[slot + 1] - sec_scan[slot]);
+    uint8_t *dst = bytes + dst_off;
+
+    U x[4];
+    load_section<ETYPE>(values, e0, valid, lane, x);
+    const SecPlan<U> p = plan_section<ETYPE>(x, lane);
+    if (p.kind == K_NULL) { // NullFixedSect::write (src/section.rs:440-443)
+        if (lane == 0) dst[0] = (uint8_t)K_NULL;
+        return;
+    }
+    if (p.kind == K_CONST) { // ConstFixedSect::write (src/section.rs:795-803): values[0], not min
+        if (lane == 0) {
+            dst[0] = (uint8_t)K_CONST;
+            if constexpr (W == 4) *(u32u *)(dst + 1) = p.first; else *(u64u *)(dst + 1) = p.first;
+        }
+        return;
+    }
+    uint32_t *buf = s_buf[wave];
+    uint8_t *bufb = (uint8_t *)buf;
+    const uint32_t ndw = (size + 3) / 4 + 1;
+    for (uint32_t d = lane; d < ndw; d += 64) buf[d] = 0;
+    const uint32_t hdr = p.kind == K_DELTA ? DELTA_HDR : 3;
+    if (lane == 0) {
+        bufb[0] = (uint8_t)p.kind;
+        // NP / Delta: bytes after the header; Xor: total including the 3 header bytes
+        // (src/section.rs:579-581, :659-661, :745-748)
+        const uint32_t len16 = p.kind == K_XOR ? size : size - hdr;
+        bufb[1] = (uint8_t)len16; bufb[2] = (uint8_t)(len16 >> 8);
+        if (p.kind == K_DELTA) {
+            bufb[3] = (uint8_t)bitlen_u((U)(p.maxv - p.minv));          // src/section.rs:663
+            for (int i = 0; i < W; i++) bufb[4 + i] = (uint8_t)(p.minv >> (8 * i)); // base; bytes 4+W..11 stay 0
+        }
+    }
+    transform_section<ETYPE>(x, p.kind, p.minv, lane);
+    const uint32_t g = lane >> 3, j = lane & 7;
+    uint32_t carry = hdr;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const OctInfo o = octet_info<U>(x[i], lane);
+        // exclusive scan of the octet sizes of groups 0..7 of this register
+        uint32_t incl = o.size;
+        uint32_t y = __shfl_up(incl, 8, 64);  if (g >= 1) incl += y;
+        y = __shfl_up(incl, 16, 64);          if (g >= 2) incl += y;
+        y = __shfl_up(incl, 32, 64);          if (g >= 4) incl += y;
+        const uint32_t off = carry + incl - o.size;
+        carry += __shfl(incl, 63, 64);
+        if (j == 0) {
+            bufb[off] = (uint8_t)o.mask;
+            if (o.mask) bufb[off + 1] = (uint8_t)(((o.n - 1) << 4) | o.t);
+        }
+        if (x[i] != 0) {
+            const uint32_t idx = __popc(o.mask & ((1u << j) - 1u));
+            const uint32_t bitpos = (off + 2) * 8 + idx * 4 * o.n;
+            const U field = x[i] >> (4 * o.t);
+            const uint32_t d = bitpos >> 5, sh = bitpos & 31;
+            if constexpr (W == 4) {
+                const uint64_t w = (uint64_t)field << sh;
+                atomicOr(&buf[d], (uint32_t)w);
+                if ((uint32_t)(w >> 32)) atomicOr(&buf[d + 1], (uint32_t)(w >> 32));
+            } else {
+                const uint64_t lo = field << sh;
+                const uint32_t hi = sh ? (uint32_t)(field >> (64 - sh)) : 0u;
+                atomicOr(&buf[d], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&buf[d + 1], (uint32_t)(lo >> 32));
+                if (hi) atomicOr(&buf[d + 2], hi);
+            }
+        }
+    }
+    // byte stores above and the atomic ORs are LDS operations of ONE wave: they complete in order,
+    // so the image is final here without a barrier.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // copy out: unaligned head bytes, aligned dwords, tail bytes
+    const uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
+    const uint32_t h = head < size ? head : size;
+    if ((uint32_t)lane < h) dst[lane] = bufb[lane];
+    const uint32_t nd = (size - h) >> 2;
+    uint32_t *dst4 = (uint32_t *)(dst + h);
+    for (uint32_t d = lane; d < nd; d += 64) dst4[d] = *(const u32u *)(bufb + h + 4 * d);
+    const uint32_t tail0 = h + 4 * nd;
+    if (tail0 + lane < size) dst[tail0 + lane] = bufb[tail0 + lane];
+}
+
+// ---- launcher --------------------------------------------------------------------------------------------
+struct EncWs {
+    uint32_t *sec_vec;
+    uint64_t *sec_size;
+    uint64_t *sec_scan;
+    uint64_t *scan_scratch;
+    size_t total;
+};
+static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
+static EncWs carve_enc_ws(void *base, uint64_t n_vectors, uint64_t n_el) {
+    const uint64_t max_slots = n_el / FIXED_LEN + n_vectors;
+    EncWs w;
+    size_t off = 0;
+    uint8_t *b = (uint8_t *)base;
+    w.sec_vec = (uint32_t *)(b + off); off += al((max_slots + 1) * 4);
+    w.sec_size = (uint64_t *)(b + off); off += al((max_slots + 1) * 8);
+    w.sec_scan = (uint64_t *)(b + off); off += al((max_slots + 2) * 8);
+    const uint64_t m = max_slots > n_vectors ? max_slots : n_vectors;
+    w.scan_scratch = (uint64_t *)(b + off); off += al(scan_scratch_words(m) * 8);
+    w.total = off;
+    return w;
+}
+size_t encode_workspace_bytes(uint64_t n_vectors, uint64_t n_el) { return carve_enc_ws(nullptr, n_vectors, n_el).total; }
+
+template <int ETYPE>
+static void launch_encode_t(const void *d_values, const uint64_t *d_elem_off, uint64_t n, uint64_t max_slots,
+                            uint8_t *d_bytes, uint64_t *d_byte_off, uint64_t *d_sec_base, uint64_t *d_result,
+                            const EncWs &w, hipStream_t stream) {
+    using U = typename EncT<ETYPE>::U;
+    const uint32_t vblocks = (uint32_t)((n + 1 + 255) / 256);
+    // sections per vector → sec_base (exclusive scan, n+1 entries)
+    k_enc_nsec<<<vblocks, 256, 0, stream>>>(d_elem_off, n, d_sec_base);
+    (void)launch_exclusive_scan(d_sec_base, n, d_sec_base, w.scan_scratch, stream);
+    if (max_slots > 0) {
+        k_enc_map<<<vblocks, 256, 0, stream>>>(d_sec_base, n, w.sec_vec);
+        const uint32_t sblocks = (uint32_t)((max_slots + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
+        k_enc_sizes<ETYPE><<<sblocks, ENC_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
+                                                                max_slots, w.sec_size);
+        (void)launch_exclusive_scan(w.sec_size, max_slots, w.sec_scan, w.scan_scratch, stream);
+        k_enc_headers<<<vblocks, 256, 0, stream>>>(ETYPE, d_elem_off, d_sec_base, w.sec_scan, n, d_bytes, d_byte_off,
+                                                   d_result);
+        k_enc_emit<ETYPE><<<sblocks, ENC_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
+                                                               max_slots, w.sec_scan, d_bytes);
+    } else {
+        (void)hipMemsetAsync(w.sec_scan, 0, 16, stream);
+        k_enc_headers<<<vblocks, 256, 0, stream>>>(ETYPE, d_elem_off, d_sec_base, w.sec_scan, n, d_bytes, d_byte_off,
+                                                   d_result);
+    }
+}
+
+hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
+                         uint64_t n_elements_total, uint8_t *d_bytes, size_t bytes_cap, uint64_t *d_byte_off,
+                         uint64_t *d_sec_base, uint64_t *d_result, void *d_workspace, size_t workspace_bytes,
+                         hipStream_t stream) {
+    (void)bytes_cap; (void)workspace_bytes;
+    const EncWs w = carve_enc_ws(d_workspace, n_vectors, n_elements_total);
+    const uint64_t max_slots = n_elements_total / FIXED_LEN + n_vectors;
+    switch (etype) {
+    case CVEC_U32: launch_encode_t<CVEC_U32>(d_values, d_elem_off, n_vectors, max_slots, d_bytes, d_byte_off, d_sec_base, d_result, w, stream); break;
+    case CVEC_U64: launch_encode_t<CVEC_U64>(d_values, d_elem_off, n_vectors, max_slots, d_bytes, d_byte_off, d_sec_base, d_result, w, stream); break;
+    case CVEC_F32: launch_encode_t<CVEC_F32>(d_values, d_elem_off, n_vectors, max_slots, d_bytes, d_byte_off, d_sec_base, d_result, w, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace cvec

@@ -1,0 +1,59 @@
+"""Synthetic inputs of the reference's `cargo bench vector` workloads (benches/bench.rs:45-56,
+:131-170), generated in float32 like the reference does.  Vector v of a batch is phase-shifted by
+37*v so that the vectors of a batch differ."""
+import math
+
+import numpy as np
+
+VECTOR_LENGTH = 10000          # benches/bench.rs:131
+PHASE_STEP = 37
+
+
+def sinewave_varnonzeros_u32(fract_nonzeroes, length, phase=0):
+    """benches/bench.rs:45-56: a sinusoid of period 20 scaled so that roughly `fract_nonzeroes` of the
+    values are positive, truncated to u32 (negatives become 0)."""
+    amp = np.float32(7.0) / np.float32(fract_nonzeroes)
+    dist = np.float32(15.0) - amp
+    i = (np.arange(length, dtype=np.int64) + phase).astype(np.float32)
+    s = np.sin(i * np.float32(math.pi) / np.float32(10.0), dtype=np.float32)
+    v = s * amp + dist
+    return np.where(v >= 0, v, 0).astype(np.uint32)
+
+
+def batch_values(kind, n_vectors, length):
+    """Values of a whole batch as one flat array + elem_off.  kind: 'u32_dense' (bench.rs:133-137),
+    'f32_xor' (bench.rs:146-151: 60 % density, /1.4), 'u64_delta' (bench.rs:153-158: +100000)."""
+    out_dtype = {"u32_dense": np.uint32, "f32_xor": np.float32, "u64_delta": np.uint64}[kind]
+    vals = np.empty(n_vectors * length, dtype=out_dtype)
+    for v in range(n_vectors):
+        if kind == "u32_dense":
+            x = sinewave_varnonzeros_u32(1.0, length, PHASE_STEP * v)
+        elif kind == "f32_xor":
+            x = sinewave_varnonzeros_u32(0.6, length, PHASE_STEP * v).astype(np.float32) / np.float32(1.4)
+        else:
+            x = sinewave_varnonzeros_u32(1.0, length, PHASE_STEP * v).astype(np.uint64) + np.uint64(100000)
+        vals[v * length:(v + 1) * length] = x
+    elem_off = (np.arange(n_vectors + 1, dtype=np.uint64) * np.uint64(length))
+    return vals, elem_off
+
+
+def batch_values_torch(kind, n_vectors, length, device="cuda"):
+    """Same generator evaluated on the device with torch (float32 math), for batches too large to
+    build on the host quickly.  Returns (values tensor, elem_off tensor int64)."""
+    import torch
+    f = 0.6 if kind == "f32_xor" else 1.0
+    amp = np.float32(7.0) / np.float32(f)
+    dist = np.float32(15.0) - amp
+    idx = torch.arange(length, device=device, dtype=torch.int64)[None, :] + \
+        PHASE_STEP * torch.arange(n_vectors, device=device, dtype=torch.int64)[:, None]
+    s = torch.sin(idx.to(torch.float32) * float(np.float32(math.pi)) / 10.0)
+    v = s * float(amp) + float(dist)
+    u = torch.where(v >= 0, v, torch.zeros_like(v)).to(torch.int64)     # truncation toward zero
+    if kind == "u32_dense":
+        vals = u.to(torch.int32)
+    elif kind == "f32_xor":
+        vals = u.to(torch.float32) / float(np.float32(1.4))
+    else:
+        vals = u + 100000
+    elem_off = torch.arange(n_vectors + 1, device=device, dtype=torch.int64) * length
+    return vals.reshape(-1).contiguous(), elem_off

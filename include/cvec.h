@@ -1,0 +1,167 @@
+/*
+ * cvec.h — C ABI of the MI355X-native NibblePack / XOR / delta path of compressed_vec.
+ *
+ * The reference crate (velvia/compressed-vec 0.1.1) exports no FFI (its Cargo.toml:43 builds a
+ * cdylib but no `extern "C"` item exists); its seams are Rust traits resolved at compile time.
+ * This header is the boundary a maintainer's `ffi.rs` would bind so that the crate keeps its API
+ * surface — VectorF32XorAppender::encode_all (src/vector.rs:238), VectorReader::decode_to_sink
+ * (src/vector.rs:458), reader.filter_iter(..) + filter::count_hits (src/vector.rs:447,
+ * src/filter.rs:296) and the sink stack (src/sink.rs:135-320) — while the work runs in HIP
+ * kernels on gfx950.  One 8 KiB vector is far below GPU launch granularity, so every entry point is
+ * batch-granular: a batch is n reference-format vectors stored back to back in one byte blob plus
+ * `byte_off[n+1]` (vector v occupies bytes [byte_off[v], byte_off[v+1])).  The bytes of each vector
+ * are exactly what the reference appender's finish() returns (16-byte header + 256-element
+ * sections; src/vector.rs:51-58, :163-186, src/section.rs:32-38).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  `d_` parameters are device pointers, `h_` host pointers.
+ *  - Every function returns a cvec_status: 0 = OK, 1..8 = the reference's CodingError discriminant
+ *    (src/error.rs:2-11), >= 100 = errors of this library (HIP failures, bad arguments).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  `_dev` functions only
+ *    enqueue work; results are valid after the stream is synchronised.
+ *  - No exceptions or panics cross this boundary.
+ */
+#ifndef CVEC_H
+#define CVEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t cvec_status;
+
+/* src/error.rs:2-11 */
+enum {
+    CVEC_OK = 0,
+    CVEC_NOT_ENOUGH_SPACE = 1,
+    CVEC_INPUT_TOO_SHORT = 2,
+    CVEC_BAD_OFFSET = 3,
+    CVEC_INVALID_SECTION_TYPE = 4,
+    CVEC_INVALID_FORMAT = 5,
+    CVEC_INVALID_NUM_ROWS = 6,
+    CVEC_WRONG_VECTOR_TYPE = 7,
+    CVEC_SCROLL_ERR = 8,
+    /* library-level */
+    CVEC_ERR_SECTION_COUNT = 100, /* sections found != ceil(header.num_elements / 256) */
+    CVEC_ERR_BAD_ARGUMENT = 101,
+    CVEC_ERR_HIP = 102,           /* a HIP runtime call failed; see cvec_last_hip_error() */
+    CVEC_ERR_NO_DEVICE = 103,
+    CVEC_ERR_WORKSPACE = 104      /* workspace too small */
+};
+
+/* Element type = the vector header's minor-type byte (src/vector.rs:94-96). */
+enum { CVEC_U64 = 0x10, CVEC_U32 = 0x11, CVEC_F32 = 0x12 };
+
+/* Predicates of the filter path: EqualsSink (src/filter.rs:129-139) and OneOfSink (:143-177).
+ * Values are raw little-endian bits of the element type (f32 compares with IEEE ==). */
+enum { CVEC_PRED_EQ = 0, CVEC_PRED_ONEOF = 1 };
+#define CVEC_MAX_PRED_VALUES 16
+typedef struct cvec_pred {
+    int32_t kind;
+    uint32_t count; /* 1 for EQ, 1..CVEC_MAX_PRED_VALUES for ONEOF */
+    uint64_t values[CVEC_MAX_PRED_VALUES];
+} cvec_pred;
+
+/* The sink stack applied to every decoded octet before it is stored (src/sink.rs).  XorSink
+ * (src/sink.rs:241-284) is implied by an Xor section and the Delta add by a Delta section, exactly
+ * as src/section.rs:707 and :637 do; the caller only chooses whether an AddConstSink
+ * (src/sink.rs:289-320) sits in front of the final VecSink (src/sink.rs:151-182). */
+typedef struct cvec_sink_chain {
+    int32_t add_const;        /* 0 = VecSink only; 1 = AddConstSink(add_const_bits) -> VecSink */
+    int32_t _pad;
+    uint64_t add_const_bits;  /* raw bits of the element type */
+} cvec_sink_chain;
+
+/* A batch resident in device memory.  `sec_base[v]` is the number of 256-element sections of all
+ * vectors before v (exclusive scan of ceil(num_elements/256) over the headers), so section k of
+ * vector v has the global slot sec_base[v] + k and its decoded elements live at
+ * out[256 * (sec_base[v] + k) ...] — VecSink's "whole sections" layout (src/sink.rs:149), vectors
+ * back to back.  `d_bytes` must be 16-byte aligned. */
+typedef struct cvec_dbatch_view {
+    int32_t etype;
+    int32_t _pad;
+    uint64_t n_vectors;
+    uint64_t n_sections;
+    uint64_t n_bytes;
+    const uint8_t *d_bytes;
+    const uint64_t *d_byte_off; /* n_vectors + 1 */
+    const uint64_t *d_sec_base; /* n_vectors + 1 */
+} cvec_dbatch_view;
+
+/* Result block written by the _dev operations (device memory, 4 x u64):
+ * [0] total match count (filter) / total elements stored (decode) / total bytes (encode)
+ * [1] number of vectors whose status != OK    [2] largest status code seen    [3] reserved */
+#define CVEC_RESULT_WORDS 4
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *cvec_version(void);
+/* Selects the device for the calling thread and warms the code object. */
+cvec_status cvec_init(int device);
+const char *cvec_last_hip_error(void);
+const char *cvec_status_name(cvec_status s);
+
+/* ---- device-resident operations ----------------------------------------------------------- */
+
+/* Bytes of scratch the _dev operations need for a batch of this shape. */
+size_t cvec_workspace_bytes(uint64_t n_vectors, uint64_t n_sections);
+
+/* Computes sec_base[n_vectors+1] from the vector headers (u32 num_elements at +8,
+ * src/vector.rs:165) on the device; also returns the section total through h_n_sections (this
+ * call synchronises the stream).  Done once per batch, like building byte_off. */
+cvec_status cvec_sec_base_dev(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_vectors,
+                              uint64_t *d_sec_base, uint64_t *h_n_sections, void *stream);
+
+/* reader.filter_iter(pred) + filter::count_hits for every vector of the batch, with the predicate
+ * fused into the decode (no decoded vector is written).  Replaces src/vector.rs:447 +
+ * src/filter.rs:189-231, :296-299.  d_result: CVEC_RESULT_WORDS u64.  d_per_vector (nullable):
+ * n_vectors u64 match counts (counts include the zero padding of the last section, as the
+ * reference's do).  d_status (nullable): n_vectors int32 status codes.  d_masks (nullable):
+ * n_sections * 32 bytes, the 256-bit mask the reference's VectorFilter yields per section
+ * (byte = octet, LSB = first element; src/filter.rs:46, :95-101). */
+cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
+                                  uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                  void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of the batch.
+ * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out holds 256 * n_sections
+ * elements of the batch's type (layout: see cvec_dbatch_view). */
+cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
+                            uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
+                            void *stream);
+
+/* Vector{U32,U64,F32Xor}Appender::encode_all for n_vectors vectors: vector v's elements are
+ * d_values[elem_off[v] .. elem_off[v+1]).  Replaces src/vector.rs:238-246 (append → encode_section
+ * → finish) with AutoEncoder (src/section.rs:819-846) for u32/u64 and XorNPMedFixedSect
+ * (src/section.rs:716-754) for f32.  Writes the blob to d_bytes (capacity bytes_cap, must be
+ * >= cvec_max_encoded_bytes), d_byte_off[n+1] and d_sec_base[n+1]; d_result[0] = blob size. */
+size_t cvec_max_encoded_bytes(int32_t etype, uint64_t n_vectors, uint64_t n_elements_total);
+size_t cvec_encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
+cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
+                            uint64_t n_elements_total, uint8_t *d_bytes, size_t bytes_cap, uint64_t *d_byte_off,
+                            uint64_t *d_sec_base, uint64_t *d_result, void *d_workspace, size_t workspace_bytes,
+                            void *stream);
+
+/* ---- host-buffer convenience (what a Rust ffi.rs shim behind the unchanged crate API calls) -- */
+/* Each call uploads through pinned staging, runs the _dev operation and downloads the result.   */
+
+cvec_status cvec_filter_count_batch(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off,
+                                    uint64_t n_vectors, const cvec_pred *pred, uint64_t *h_total,
+                                    uint64_t *h_per_vector /*nullable*/, int32_t *h_status /*nullable*/);
+
+/* h_out: 256 * (sum of ceil(num_elements/256)) elements; h_out_off (nullable, n+1) receives each
+ * vector's first element index in h_out. */
+cvec_status cvec_decode_batch(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off,
+                              uint64_t n_vectors, const cvec_sink_chain *chain, void *h_out, uint64_t out_cap_elems,
+                              uint64_t *h_out_off /*nullable*/, int32_t *h_status /*nullable*/);
+
+cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_t *h_elem_off, uint64_t n_vectors,
+                              uint8_t *h_bytes, size_t bytes_cap, uint64_t *h_byte_off /* n+1 */,
+                              uint64_t *h_total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVEC_H */

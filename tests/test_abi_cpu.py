@@ -1,0 +1,88 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/cvec.h
+declares (no compute calls here), and the host logic that needs no GPU behaves like the reference."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cvec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cvec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import compressed_vec_amd as cv
+    from compressed_vec_amd import _native
+    if not os.path.exists(cv.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = cv.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), "missing export " + name
+    assert sorted(_native.SIGNATURES) == declared
+    assert b"gfx950" in lib.cvec_version()
+    assert lib.cvec_status_name(7) == b"WrongVectorType"
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from compressed_vec_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libcvec_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_workspace_and_capacity_formulas():
+    import compressed_vec_amd as cv
+    lib = cv.lib()
+    assert lib.cvec_workspace_bytes(0, 0) > 0
+    assert lib.cvec_workspace_bytes(1000, 8000) >= 8000 * 12 + 1000 * 4
+    # worst case: every section is a Delta section of 32 full-width octets
+    assert lib.cvec_max_encoded_bytes(cv.U32, 1, 256) >= 16 + 12 + 32 * 34
+    assert lib.cvec_max_encoded_bytes(cv.U64, 1, 256) >= 16 + 12 + 32 * 66
+    assert lib.cvec_encode_workspace_bytes(10, 2560) > 0
+
+
+def test_reader_try_new_checks_match_oracle(oracle):
+    import compressed_vec_amd as cv
+    good = oracle.encode_all(oracle.U32, np.arange(400, dtype=np.uint32))
+    cases = [good, good[:0], good[:3], good[:5], good[:10], good[:len(good) - 1]]
+    bad = bytearray(good)
+    bad[5] = 0x12
+    cases.append(bytes(bad))
+    for b in cases:
+        rc, _ = oracle.reader_check(oracle.U32, b)
+        if rc == 0:
+            assert cv.VectorReader.try_new(b, "u32").num_elements() == 400
+        else:
+            with pytest.raises(cv.CodingError) as e:
+                cv.VectorReader.try_new(b, "u32")
+            assert e.value.code == rc
+
+
+def test_appender_argument_errors():
+    import compressed_vec_amd as cv
+    a = cv.VectorU32Appender.try_new(1024)
+    a.append_many(np.arange(10, dtype=np.uint32))
+    with pytest.raises(cv.CodingError) as e:
+        a.finish(5)
+    assert e.value.name == "InvalidNumRows" and e.value.detail == (5, 10)
+    with pytest.raises(cv.CodingError):
+        cv.make_pred(cv.U32, list(range(17)))
+
+
+def test_synth_generator_matches_bench_shape():
+    from compressed_vec_amd import synth
+    v = synth.sinewave_varnonzeros_u32(1.0, 10000)
+    assert v.min() >= 1 and v.max() <= 15                      # benches/bench.rs:133: "values 1..15"
+    s = synth.sinewave_varnonzeros_u32(0.6, 10000)
+    assert 0.5 < (s != 0).mean() < 0.7                          # ~60 % density
+    vals, eo = synth.batch_values("u64_delta", 3, 100)
+    assert vals.dtype == np.uint64 and vals.min() > 100000 and list(eo) == [0, 100, 200, 300]

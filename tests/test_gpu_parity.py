@@ -1,0 +1,324 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every check goes through the C ABI of
+include/cvec.h and compares against the CPU oracle on the same seeded inputs: bit-exact for encoded
+bytes, decoded values (f32 compared as raw bits), masks and counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import compressed_vec_amd as cv
+    assert cv.lib().cvec_init(0) == 0
+    return cv
+
+
+ET = {"u32": 0x11, "u64": 0x10, "f32": 0x12}
+NPD = {"u32": np.uint32, "u64": np.uint64, "f32": np.float32}
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64)
+
+
+def _random_vectors(rng, tname, n_vectors, max_len=1500):
+    """Ragged vectors mixing every section kind: zeros, constants, narrow ranges around a big base,
+    wide values, sparse values."""
+    vals, off = [], [0]
+    for _ in range(n_vectors):
+        n = int(rng.integers(0, max_len))
+        parts = []
+        left = n
+        while left > 0:
+            k = int(min(left, rng.integers(1, 700)))
+            mode = rng.integers(0, 6)
+            if tname == "f32":
+                if mode == 0:
+                    p = np.zeros(k, dtype=np.float32)
+                elif mode == 1:
+                    p = np.full(k, rng.normal() * 100, dtype=np.float32)
+                elif mode == 2:
+                    p = (rng.integers(0, 16, size=k) / np.float32(1.4)).astype(np.float32)
+                elif mode == 3:
+                    p = rng.normal(size=k).astype(np.float32)
+                elif mode == 4:
+                    p = (rng.integers(0, 1 << 20, size=k).astype(np.float32) * np.float32(0.25))
+                else:
+                    p = rng.normal(size=k).astype(np.float32)
+                    p[rng.random(k) < 0.7] = 0
+            else:
+                bits = 32 if tname == "u32" else 64
+                if mode == 0:
+                    p = np.zeros(k, dtype=np.uint64)
+                elif mode == 1:
+                    p = np.full(k, rng.integers(1, 1 << 31), dtype=np.uint64)
+                elif mode == 2:
+                    p = rng.integers(1, 16, size=k).astype(np.uint64)
+                elif mode == 3:
+                    nb = int(rng.integers(4, bits))
+                    p = rng.integers(0, 1 << nb, size=k, dtype=np.uint64)
+                elif mode == 4:
+                    base = int(rng.integers(1 << 16, 1 << (bits - 2)))
+                    p = (rng.integers(0, 1 << int(rng.integers(2, 14)), size=k).astype(np.uint64) + np.uint64(base))
+                else:
+                    nb = int(rng.integers(4, bits))
+                    p = rng.integers(0, 1 << nb, size=k, dtype=np.uint64)
+                    p[rng.random(k) < 0.7] = 0
+                p = p.astype(NPD[tname])
+            parts.append(p)
+            left -= k
+        v = np.concatenate(parts) if parts else np.zeros(0, dtype=NPD[tname])
+        vals.append(v.astype(NPD[tname]))
+        off.append(off[-1] + v.size)
+    flat = np.concatenate(vals) if vals else np.zeros(0, dtype=NPD[tname])
+    return flat, np.array(off, dtype=np.uint64)
+
+
+def test_unaligned_loads_and_library_loads(cv):
+    assert b"gfx950" in cv.lib().cvec_version()
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_hand_derived_vectors_through_gpu_encoder(cv, kats, tname):
+    for k in kats["hand_derived_vectors"]:
+        if k["type"] != tname:
+            continue
+        vals = np.array(k["values"], dtype=NPD[tname])
+        b = cv.encode_batch(tname, vals, np.array([0, vals.size], dtype=np.uint64))
+        assert list(b.vector(0)) == k["expected"], k["src"]
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_encode_bytes_bit_exact_vs_oracle(cv, oracle, tname):
+    rng = np.random.default_rng(100 + ET[tname])
+    vals, eo = _random_vectors(rng, tname, 300)
+    want_blob, want_off = oracle.batch_encode(ET[tname], vals, eo)
+    got = cv.encode_batch(tname, vals, eo)
+    assert np.array_equal(got.byte_off, want_off)
+    assert np.array_equal(got.blob, want_blob)
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_decode_bit_exact_vs_oracle(cv, oracle, tname):
+    rng = np.random.default_rng(200 + ET[tname])
+    vals, eo = _random_vectors(rng, tname, 300)
+    blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+    dev = cv.EncodedBatch(tname, blob, bo).to_device()
+    got, out_off = dev.decode()
+    want, st, rc = oracle.batch_decode(ET[tname], blob, bo, out_off)
+    assert rc == 0
+    assert np.array_equal(_bits(got), _bits(want))
+    # round trip: the first num_elements values of every vector are the inputs
+    for v in range(eo.size - 1):
+        n = int(eo[v + 1] - eo[v])
+        a = got[int(out_off[v]):int(out_off[v]) + n]
+        assert np.array_equal(_bits(a), _bits(vals[int(eo[v]):int(eo[v + 1])])) or tname == "f32"
+    # AddConstSink in front of VecSink
+    base = {"u32": 4000000000, "u64": (1 << 63) + 12345, "f32": 2.5}[tname]
+    got2, _ = dev.decode(add_const=base)
+    want2, _, rc = oracle.batch_decode(ET[tname], blob, bo, out_off, add_base=base)
+    assert rc == 0
+    assert np.array_equal(_bits(got2), _bits(want2))
+
+
+def test_f32_roundtrip_is_bitwise_unless_section_is_lossy(cv, oracle):
+    """XOR sections are bitwise; only the writer's Const/Null choice (min == max under float ==) can
+    alter bits (-0.0 / NaN), and the GPU encoder must make exactly the oracle's choice."""
+    rng = np.random.default_rng(7)
+    vals = rng.normal(size=256 * 40).astype(np.float32)
+    vals[256:512] = 0.0
+    vals[300] = -0.0                       # mixed zeros → Null section (decodes to +0.0)
+    vals[512:768] = 5.0
+    vals[513] = np.nan                     # NaN hidden by the fold → lossy Const section
+    vals[768:1024] = 7.0
+    vals[1023] = np.nan                    # trailing NaN → max = NaN → Xor section, bitwise
+    vals[1024] = np.nan                    # leading NaN → min = NaN → Xor
+    vals[1280:1536] = -0.0                 # all -0.0 → min == max == 0 → Null
+    eo = np.array([0, vals.size], dtype=np.uint64)
+    want_blob, want_off = oracle.batch_encode(0x12, vals, eo)
+    got = cv.encode_batch("f32", vals, eo)
+    assert np.array_equal(got.blob, want_blob)
+    dec, _ = got.to_device().decode()
+    assert np.array_equal(_bits(dec), _bits(oracle.decode_to_vec(0x12, want_blob)))
+    assert np.array_equal(_bits(dec[:256]), _bits(vals[:256]))
+    assert np.array_equal(_bits(dec[768:1280]), _bits(vals[768:1280]))
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_filter_count_and_masks_vs_oracle(cv, oracle, tname):
+    rng = np.random.default_rng(300 + ET[tname])
+    vals, eo = _random_vectors(rng, tname, 200)
+    blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+    dev = cv.EncodedBatch(tname, blob, bo).to_device()
+    nz = vals[vals != 0]
+    preds = [0, nz[len(nz) // 3], nz[len(nz) // 2], [nz[5], 0, nz[77]], [nz[1], nz[2], nz[3], nz[4], nz[9]]]
+    if tname == "f32":
+        preds += [-0.0, float("nan"), np.float32(5) / np.float32(1.4)]
+    else:
+        preds += [3, [3, 5]]
+    for p in preds:
+        total, per, st, masks = dev.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+        wtotal, wper, wst, rc = oracle.batch_filter_count(ET[tname], blob, bo, p)
+        assert rc == 0 and np.all(st == 0)
+        assert total == wtotal, p
+        assert np.array_equal(per, wper), p
+        # per-section masks of a few vectors
+        sb = dev.d_sec_base.cpu().numpy()
+        for v in range(0, eo.size - 1, 37):
+            _, wm = oracle.filter_count(ET[tname], blob[int(bo[v]):int(bo[v + 1])], p, return_masks=True)
+            gm = masks[32 * int(sb[v]):32 * int(sb[v + 1])]
+            assert np.array_equal(gm, wm), (p, v)
+
+
+def test_reference_test_cases_through_the_api_mirror(cv):
+    """The reference's own vector/filter tests, phrased with the same API names."""
+    # src/vector.rs:669-684
+    app = cv.VectorU32Appender.try_new(1024)
+    for i in range(400):
+        app.append((i % 4) + 1)
+    finished = app.finish(400)
+    reader = cv.VectorReader.try_new(finished, "u32")
+    assert reader.num_elements() == 400
+    assert cv.count_hits(reader.filter_iter(cv.EqualsSink("u32", 3))) == 100
+    # src/vector.rs:686-703
+    for i in range(300):
+        app.append((i % 4) + 1)
+    app.append_nulls(400)
+    for i in range(300):
+        app.append((i % 4) + 1)
+    finished = app.finish(1000)
+    reader = cv.VectorReader.try_new(finished, "u32")
+    assert cv.count_hits(reader.filter_iter(cv.EqualsSink("u32", 3))) == 150
+    sink = cv.VecSink("u32")
+    reader.decode_to_sink(sink)
+    assert list(sink.vec[:1000]) == list(reader.iterate())
+    # src/vector.rs:729-739
+    with pytest.raises(cv.CodingError) as e:
+        cv.VectorReader.try_new(finished, "u64")
+    assert e.value.name == "WrongVectorType" and e.value.detail == (0x11,)
+    # src/vector.rs:742-755
+    data = (np.arange(280, dtype=np.float32) / np.float32(2.8)).astype(np.float32)
+    fin = cv.VectorF32XorAppender.try_new(2048).encode_all(data)
+    reader = cv.VectorReader.try_new(fin, "f32")
+    assert reader.num_elements() == 280
+    sink = cv.VecSink("f32")
+    reader.decode_to_sink(sink)
+    assert sink.vec[:280].tobytes() == data.tobytes()
+    # src/filter.rs:332-348
+    fin = cv.VectorU64Appender.try_new(1024).encode_all(np.arange(400, dtype=np.uint64) % 4 + 1)
+    reader = cv.VectorReader.try_new(fin, "u64")
+    assert cv.match_positions(reader.filter_iter(cv.EqualsSink("u64", 3))) == list(range(2, 400, 4))
+    # src/filter.rs:351-371
+    fin = cv.VectorU32Appender.try_new(1024).encode_all(np.arange(400, dtype=np.uint32) % 12 + 1)
+    reader = cv.VectorReader.try_new(fin, "u32")
+    pos = cv.match_positions(reader.filter_iter(cv.OneOfSink("u32", [3, 5])))
+    assert pos == [p for i in range(2, 400, 12) for p in (i, i + 2)][:67]
+    # README.md:58-65
+    enc = cv.VectorF32XorAppender.try_new(2048).encode_all([1.0, 1.5, 2.0, 2.5])
+    reader = cv.VectorReader.try_new(enc, "f32")
+    vecsink = cv.VecSink("f32")
+    reader.decode_to_sink(cv.AddConstSink(2.5, vecsink))
+    assert list(vecsink.vec[:4]) == [3.5, 4.0, 4.5, 5.0]
+
+
+def test_mixed_null_appender_bytes_match_oracle(cv, oracle):
+    # src/vector.rs:601-634, :637-666: explicit null sections are counted in the header
+    for cap, d1n, nulls, d2n in [(1024, 100, (256 - 100) + 256 + 50, 50), (300, 300, 350, 300)]:
+        a, o = cv.VectorU64Appender.try_new(cap), oracle.Appender(oracle.U64, cap)
+        d1, d2 = np.arange(d1n, dtype=np.uint64), np.arange(d2n, dtype=np.uint64)
+        for app in (a, o):
+            app.append_many(d1)
+            app.append_nulls(nulls)
+            app.append_many(d2)
+        total = d1n + d2n + nulls
+        assert a.finish(total) == o.finish(total)
+    # finish() with more rows than appended adds explicit null sections (src/vector.rs:357-359)
+    a, o = cv.VectorU32Appender.try_new(64), oracle.Appender(oracle.U32, 64)
+    for app in (a, o):
+        app.append_many(np.arange(10, dtype=np.uint32))
+    assert a.finish(1000) == o.finish(1000)
+
+
+def test_null_section_through_addconst_keeps_base_bits(cv, oracle):
+    # src/sink.rs:314-317
+    enc = cv.VectorF32XorAppender.try_new(64).encode_all(np.zeros(300, dtype=np.float32))
+    reader = cv.VectorReader.try_new(enc, "f32")
+    s = cv.VecSink("f32")
+    reader.decode_to_sink(cv.AddConstSink(-0.0, s))
+    assert np.all(s.vec.view(np.uint32) == 0x80000000)
+
+
+def test_empty_batch_and_empty_vectors(cv, oracle):
+    for tname in ("u32", "f32"):
+        b = cv.encode_batch(tname, np.zeros(0, dtype=NPD[tname]), np.array([0], dtype=np.uint64))
+        assert b.n_vectors == 0 and b.blob.size == 0
+        vals = np.arange(5, dtype=NPD[tname])
+        eo = np.array([0, 0, 5, 5], dtype=np.uint64)
+        got = cv.encode_batch(tname, vals, eo)
+        want_blob, want_off = oracle.batch_encode(ET[tname], vals, eo)
+        assert np.array_equal(got.blob, want_blob) and np.array_equal(got.byte_off, want_off)
+        dev = got.to_device()
+        assert dev.n_sections == 1
+        assert dev.filter_count(3) == 1
+        dec, off = dev.decode()
+        assert dec.size == 256 and list(off) == [0, 0, 256, 256]
+
+
+def test_malformed_vectors_report_status_and_partial_counts(cv, oracle):
+    good = oracle.encode_all(oracle.U32, (np.arange(1000, dtype=np.uint32) % 7) + 1)
+    vecs = [good]
+    bad = bytearray(good)
+    bad[5] = 0x10                                   # wrong subtype
+    vecs.append(bytes(bad))
+    bad = bytearray(good)
+    pos = 16
+    _, nb = oracle.section_parse(oracle.U32, good[pos:])
+    bad[pos + nb] = 9                               # second section: invalid type byte
+    vecs.append(bytes(bad))
+    bad = bytearray(good)
+    bad[pos + nb + 3 + 1] = 0xf0                    # second section, first octet: 16 nibbles in a u32 vector
+    vecs.append(bytes(bad))
+    vecs.append(good[:10])                          # truncated header
+    vecs.append(good[:len(good) - 40])              # truncated body
+    xor = oracle.encode_all(oracle.F32, (np.arange(300) / 1.3).astype(np.float32))
+    bad = bytearray(xor)
+    bad[5] = 0x11                                   # an Xor section inside a vector that claims u32
+    vecs.append(bytes(bad))
+    vecs.append(good)
+    host = cv.EncodedBatch.from_vectors("u32", vecs)
+    dev = host.to_device()
+    total, per, st = dev.filter_count(3, per_vector=True, return_status=True)
+    wtotal, wper, wst, _ = oracle.batch_filter_count(oracle.U32, host.blob, host.byte_off, 3)
+    assert list(st) == list(wst)
+    assert np.array_equal(per, wper)
+    assert total == wtotal
+    assert st[0] == 0 and st[-1] == 0 and st[1] == 7 and st[2] == 4 and st[3] == 5 and st[6] == 5
+    _, _, dst = dev.decode(return_status=True)
+    assert list(dst) == list(wst)
+
+
+def test_full_size_properties_cfg5_shape(cv):
+    """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
+    decode is the identity on bits, counts are additive over predicates that partition the values,
+    and per-vector counts sum to the total."""
+    import torch
+    from compressed_vec_amd import synth
+    nvec, length = 4096, 2048
+    vals, eo = synth.batch_values_torch("f32_xor", nvec, length)
+    dev = cv.encode_device("f32", vals, eo)
+    out = torch.zeros(dev.n_sections * 256, dtype=torch.float32, device="cuda")
+    dev.decode_async(out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), vals.view(torch.int32))
+    distinct = torch.unique(vals).cpu().numpy()
+    total = 0
+    for d in distinct:
+        total += dev.filter_count(float(d))
+    assert total == nvec * length
+    t, per = dev.filter_count(float(distinct[3]), per_vector=True)
+    assert int(per.sum()) == t
+    assert dev.filter_count([float(x) for x in distinct[:8]]) == sum(dev.filter_count(float(x)) for x in distinct[:8])
