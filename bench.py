@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident decode+filter throughput on f32 XOR-encoded vectors.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one fused decode+filter+count pass (reader.filter_iter(EqualsSink(3.0)) + count_hits,
+benches/bench.rs:238-241 of the reference) over the rank's whole batch, which is already resident in
+HBM; for N > 1 every rank owns its own shard of vectors (no data exchange) and the step ends with one
+RCCL all-reduce of the 8-byte match count.  Workload: 131072 vectors x 2048 f32 per GPU (1 GiB of
+uncompressed values per GPU; at N = 8 this is BASELINE.json's config 5: 1 Mi vectors of 2048).
+Rank 0 prints one JSON line; `value` is whole-job GB/s counted in uncompressed bytes."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+VEC_LEN = 2048
+VECS_PER_GPU = 131072
+PRED = 3.0                     # benches/bench.rs:239
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--vectors-per-gpu", type=int, default=VECS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the encode / decode / PCIe side measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(dev_batch, n_sample_vectors, seconds, pred):
+    """Times the CPU oracle (scalar C restatement of the reference path, one thread) on the first
+    vectors of the same batch."""
+    import torch
+    import oracle
+    oracle.build()
+    n = min(n_sample_vectors, dev_batch.n_vectors)
+    bo = dev_batch.d_byte_off[:n + 1].cpu().numpy().view(np.uint64).copy()
+    blob = dev_batch.d_bytes[:int(bo[-1])].cpu().numpy()
+    elems = n * VEC_LEN
+    passes, t0 = 0, time.perf_counter()
+    total = None
+    while True:
+        total, _, _, rc = oracle.batch_filter_count(oracle.F32, blob, bo, pred)
+        assert rc == 0
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    gbs = passes * elems * 4 / dt / 1e9
+    return {"value": round(gbs, 4), "unit": "GB/s (uncompressed bytes)", "cores": 1, "kind": "port",
+            "sample": "first %d of the same %d-element f32 XOR vectors (%d MiB uncompressed), %d passes in %.1f s, "
+                      "filter == %.1f + count, oracle/cvec_oracle.c single thread" %
+                      (n, VEC_LEN, elems * 4 >> 20, passes, dt, pred)}, total
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus,
+              file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import compressed_vec_amd as cv
+    from compressed_vec_amd import synth
+    from compressed_vec_amd import _native as N
+    lib = cv.lib()
+    assert lib.cvec_init(local_rank) == 0
+
+    nvec = args.vectors_per_gpu
+    # ---- build this rank's shard in HBM: generate values, encode them on the GPU ----------------------
+    v0 = rank * nvec
+    chunks = []
+    step_v = 16384
+    for c0 in range(0, nvec, step_v):
+        cn = min(step_v, nvec - c0)
+        vals, _ = synth.batch_values_torch("f32_xor", cn, VEC_LEN, v_first=v0 + c0)
+        chunks.append(vals)
+    values = torch.cat(chunks)
+    del chunks
+    elem_off = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * VEC_LEN
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    batch = cv.encode_device("f32", values, elem_off)
+    torch.cuda.synchronize()
+    t_first_encode = time.perf_counter() - t0
+    n_elems = nvec * VEC_LEN
+    raw_bytes = n_elems * 4
+
+    # ---- correctness gate before timing: the count must equal a direct count on the raw values ----------
+    distinct = torch.unique(values[:1 << 20])
+    check_pred = float(distinct[distinct.numel() // 2].item())   # a value that does occur
+    got = batch.filter_count(check_pred)
+    want = int((values == check_pred).sum().item())
+    assert got == want and got > 0, "filter count %d != %d" % (got, want)
+    want_timed = int((values == PRED).sum().item())
+
+    pred = cv.make_pred(cv.F32, PRED)
+    result = batch.result_buffer()
+
+    def step():
+        batch.filter_count_async(pred, result=result)
+        if world > 1:
+            dist.all_reduce(result[:1], op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    N.check(lib.cvec_timing_begin(args.steps))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = [C.c_float(0), C.c_float(0), C.c_float(0)]
+    nrec = C.c_int32(0)
+    N.check(lib.cvec_timing_end(C.byref(ms[0]), C.byref(ms[1]), C.byref(ms[2]), C.byref(nrec)))
+    total_count = int(result[0].item())
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        wt = torch.tensor([want_timed], device="cuda", dtype=torch.int64)
+        dist.all_reduce(wt, op=dist.ReduceOp.SUM)
+        want_timed = int(wt.item())
+    assert total_count == want_timed, "timed predicate count %d != %d" % (total_count, want_timed)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * raw_bytes * args.steps / elapsed / 1e9
+    k_sections_ms = ms[1].value / max(nrec.value, 1)
+    achieved = raw_bytes / (k_sections_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "device-resident decode+filter GB/s (uncompressed bytes), f32 XOR",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "cfg5 shard: %d vectors x %d f32 per GPU, XOR+NibblePack sections, "
+                               "filter == %.1f + count_hits%s" % (nvec, VEC_LEN, PRED,
+                                                                  ", RCCL all-reduce of the count" if world > 1 else ""),
+                   "vectors_per_gpu": nvec, "vector_len": VEC_LEN, "parallelism": "shard%d" % world,
+                   "compressed_bytes_per_gpu": batch.n_bytes,
+                   "compressed_bytes_per_element": round(batch.n_bytes / n_elems, 4)},
+    }
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("vectors_per_gpu") == nvec:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "k_sections<f32, filter>",
+                           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "algorithmic_bytes_per_launch": raw_bytes,
+                           "avg_launch_ms": round(k_sections_ms, 4),
+                           "other_kernels_ms": {"k_index": round(ms[0].value / max(nrec.value, 1), 4),
+                                                "k_finalize": round(ms[2].value / max(nrec.value, 1), 4)}}
+        if not args.no_cpu_baseline:
+            cb, cpu_total = cpu_baseline(batch, 4096, args.cpu_seconds, PRED)
+            out["cpu_baseline"] = cb
+        if not args.no_extra:
+            out["extra"] = side_measurements(torch, cv, batch, values, elem_off, raw_bytes)
+            out["extra"]["first_encode_call_s"] = round(t_first_encode, 4)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _time_gpu(torch, fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
+    """Reported next to the headline, outside the timed region: decode through the sink stack into a
+    buffer, encode, and the host-inclusive (pinned H2D / D2H) filter rate."""
+    ex = {}
+    out = torch.empty(batch.n_sections * 256, dtype=torch.float32, device="cuda")
+    t = _time_gpu(torch, lambda: batch.decode_async(out, add_const=2.5), 10)
+    ex["decode_addconst_vecsink_GBs"] = round(raw_bytes / t / 1e9, 2)
+    ok = torch.equal((values + 2.5).view(torch.int32), out[:values.numel()].view(torch.int32))
+    ex["decode_bit_exact_vs_input"] = bool(ok)
+    del out
+    t = _time_gpu(torch, lambda: cv.encode_device("f32", values, elem_off), 5)
+    ex["encode_all_GBs"] = round(raw_bytes / t / 1e9, 2)
+    # host-inclusive: encoded bytes start in pinned host memory, count ends in host memory
+    host_blob = torch.empty(batch.n_bytes, dtype=torch.uint8).pin_memory()
+    host_blob.copy_(batch.d_bytes[:batch.n_bytes])
+    host_off = batch.d_byte_off.cpu().pin_memory()
+    torch.cuda.synchronize()
+    d_bytes = torch.empty_like(batch.d_bytes)
+    d_off = torch.empty_like(batch.d_byte_off)
+    res_host = torch.empty(4, dtype=torch.int64).pin_memory()
+
+    def host_inclusive():
+        d_bytes[:batch.n_bytes].copy_(host_blob, non_blocking=True)
+        d_off.copy_(host_off, non_blocking=True)
+        b = cv.DeviceBatch(cv.F32, d_bytes, d_off, batch.d_sec_base, batch.n_vectors, batch.n_sections, batch.n_bytes)
+        b._ws = batch.workspace()
+        r = b.filter_count_async(PRED)
+        res_host.copy_(r, non_blocking=True)
+        torch.cuda.synchronize()
+
+    t = _time_gpu(torch, host_inclusive, 3)
+    ex["host_inclusive_filter_GBs"] = round(raw_bytes / t / 1e9, 2)
+    ex["host_inclusive_note"] = "pinned H2D of the encoded bytes + filter + D2H of the count, uncompressed bytes / wall"
+    return ex
+
+
+if __name__ == "__main__":
+    main()

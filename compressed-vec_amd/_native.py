@@ -57,6 +57,9 @@ SIGNATURES = {
     "cvec_init": (C.c_int32, [C.c_int]),
     "cvec_last_hip_error": (C.c_char_p, []),
     "cvec_status_name": (C.c_char_p, [C.c_int32]),
+    "cvec_timing_begin": (C.c_int32, [C.c_int32]),
+    "cvec_timing_end": (C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                    C.POINTER(C.c_int32)]),
     "cvec_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
     "cvec_sec_base_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64),
                                       C.c_void_p]),

@@ -14,6 +14,8 @@ uint64_t scan_scratch_words(uint64_t n);
 hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
                        uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
                        int32_t *d_status, uint8_t *d_masks, void *d_out, hipStream_t stream);
+hipError_t timing_begin(int max_records);
+hipError_t timing_end(float ms[3], int *n_records);
 // cvec_encode.hip
 size_t encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
 hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
@@ -112,6 +114,23 @@ cvec_status cvec_init(int device) {
     if (device < 0 || device >= count) return CVEC_ERR_BAD_ARGUMENT;
     HIP_TRY(hipSetDevice(device));
     (void)hipFree(nullptr);
+    return CVEC_OK;
+}
+
+cvec_status cvec_timing_begin(int32_t max_records) {
+    if (max_records <= 0 || max_records > 4096) return CVEC_ERR_BAD_ARGUMENT;
+    HIP_TRY(timing_begin(max_records));
+    return CVEC_OK;
+}
+
+cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_finalize, int32_t *n_records) {
+    float ms[3];
+    int n = 0;
+    HIP_TRY(timing_end(ms, &n));
+    if (ms_index) *ms_index = ms[0];
+    if (ms_sections) *ms_sections = ms[1];
+    if (ms_finalize) *ms_finalize = ms[2];
+    if (n_records) *n_records = n;
     return CVEC_OK;
 }
 

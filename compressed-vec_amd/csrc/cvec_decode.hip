@@ -13,6 +13,8 @@
 //               per lane, undoes XOR with a wavefront scan and either compares (filter) or stores.
 //   k_finalize  one lane per vector folds its sections' results in order, so a failing section
 //               ends that vector exactly where the reference's iteration would stop.
+#include <vector>
+
 #include "cvec_device.hpp"
 
 namespace cvec {
@@ -481,6 +483,55 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ s
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+
+// Optional per-kernel timing of the read path: when armed, every launch_read records a pair of HIP
+// events around each of its three kernels on the launch stream.
+struct KernelTimer {
+    std::vector<hipEvent_t> ev; // 6 per record: index start/stop, sections start/stop, finalize start/stop
+    int capacity = 0, used = 0;
+    bool armed = false;
+};
+static KernelTimer g_timer;
+
+hipError_t timing_begin(int max_records) {
+    for (hipEvent_t e : g_timer.ev) (void)hipEventDestroy(e);
+    g_timer.ev.clear();
+    g_timer.capacity = max_records;
+    g_timer.used = 0;
+    g_timer.ev.resize((size_t)max_records * 6);
+    for (auto &e : g_timer.ev) {
+        hipError_t r = hipEventCreate(&e);
+        if (r != hipSuccess) return r;
+    }
+    g_timer.armed = true;
+    return hipSuccess;
+}
+
+// Sums the elapsed milliseconds of each kernel over the recorded launches (synchronises the events).
+hipError_t timing_end(float ms[3], int *n_records) {
+    g_timer.armed = false;
+    ms[0] = ms[1] = ms[2] = 0.f;
+    for (int r = 0; r < g_timer.used; r++) {
+        for (int k = 0; k < 3; k++) {
+            hipEvent_t a = g_timer.ev[(size_t)r * 6 + 2 * k], b = g_timer.ev[(size_t)r * 6 + 2 * k + 1];
+            hipError_t e = hipEventSynchronize(b);
+            if (e != hipSuccess) return e;
+            float t = 0.f;
+            e = hipEventElapsedTime(&t, a, b);
+            if (e != hipSuccess) return e;
+            ms[k] += t;
+        }
+    }
+    *n_records = g_timer.used;
+    for (hipEvent_t e : g_timer.ev) (void)hipEventDestroy(e);
+    g_timer.ev.clear();
+    g_timer.capacity = g_timer.used = 0;
+    return hipSuccess;
+}
+
+static inline void timer_mark(int rec, int which, hipStream_t stream) {
+    if (rec >= 0) (void)hipEventRecord(g_timer.ev[(size_t)rec * 6 + which], stream);
+}
 hipError_t launch_sec_base(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n, uint64_t *d_sec_base,
                            uint64_t *d_scratch /* ceil(n/SCAN_BLOCK)+1 u64 */, hipStream_t stream) {
     if (n == 0) return hipMemsetAsync(d_sec_base, 0, sizeof(uint64_t), stream);
@@ -510,8 +561,12 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
                           hipStream_t stream) {
     const uint64_t n = b.n_vectors, ns = b.n_sections;
+    const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
+    timer_mark(rec, 0, stream);
     k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
                                                                                  n, desc, vstatus, d_result);
+    timer_mark(rec, 1, stream);
+    timer_mark(rec, 2, stream);
     if (ns > 0) {
         const uint32_t ntiles = (uint32_t)((ns + TILE - 1) / TILE);
         if (mode == MODE_FILTER)
@@ -521,9 +576,12 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
             k_sections<ETYPE, MODE_DECODE><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res,
                                                                                nullptr, d_out);
     }
+    timer_mark(rec, 3, stream);
+    timer_mark(rec, 4, stream);
     if (n > 0)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,
                                                                     d_status, d_result);
+    timer_mark(rec, 5, stream);
 }
 
 hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,

@@ -37,15 +37,16 @@ def batch_values(kind, n_vectors, length):
     return vals, elem_off
 
 
-def batch_values_torch(kind, n_vectors, length, device="cuda"):
+def batch_values_torch(kind, n_vectors, length, device="cuda", v_first=0):
     """Same generator evaluated on the device with torch (float32 math), for batches too large to
-    build on the host quickly.  Returns (values tensor, elem_off tensor int64)."""
+    build on the host quickly; vector i of the result has the phase of global vector v_first + i.
+    Returns (values tensor, elem_off tensor int64)."""
     import torch
     f = 0.6 if kind == "f32_xor" else 1.0
     amp = np.float32(7.0) / np.float32(f)
     dist = np.float32(15.0) - amp
     idx = torch.arange(length, device=device, dtype=torch.int64)[None, :] + \
-        PHASE_STEP * torch.arange(n_vectors, device=device, dtype=torch.int64)[:, None]
+        PHASE_STEP * (torch.arange(n_vectors, device=device, dtype=torch.int64)[:, None] + v_first)
     s = torch.sin(idx.to(torch.float32) * float(np.float32(math.pi)) / 10.0)
     v = s * float(amp) + float(dist)
     u = torch.where(v >= 0, v, torch.zeros_like(v)).to(torch.int64)     # truncation toward zero

@@ -79,7 +79,8 @@ typedef struct cvec_sink_chain {
  * vectors before v (exclusive scan of ceil(num_elements/256) over the headers), so section k of
  * vector v has the global slot sec_base[v] + k and its decoded elements live at
  * out[256 * (sec_base[v] + k) ...] — VecSink's "whole sections" layout (src/sink.rs:149), vectors
- * back to back.  `d_bytes` must be 16-byte aligned. */
+ * back to back.  `d_bytes` must be 16-byte aligned and its allocation readable up to the next
+ * multiple of 16 bytes past n_bytes (the kernels stage the blob with 16-byte loads). */
 typedef struct cvec_dbatch_view {
     int32_t etype;
     int32_t _pad;
@@ -102,6 +103,14 @@ const char *cvec_version(void);
 cvec_status cvec_init(int device);
 const char *cvec_last_hip_error(void);
 const char *cvec_status_name(cvec_status s);
+
+/* Per-kernel timing of cvec_filter_count_dev / cvec_decode_dev for roofline accounting (no
+ * counterpart in the reference, whose benches time whole calls with criterion, benches/bench.rs:184).
+ * Between begin and end every such call records HIP events around its three kernels on its launch
+ * stream (at most max_records calls); end waits for them and returns the summed milliseconds of
+ * the section-index, section-decode and finalize kernels.  Not thread-safe; one user at a time. */
+cvec_status cvec_timing_begin(int32_t max_records);
+cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_finalize, int32_t *n_records);
 
 /* ---- device-resident operations ----------------------------------------------------------- */
 
