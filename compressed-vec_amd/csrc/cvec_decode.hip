@@ -193,51 +193,58 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
 // ------------------------------------------------------------------------------------------------
 constexpr int TILE = 32;            // section slots per workgroup
 constexpr int SEC_THREADS = 256;    // 4 waves
-constexpr int OCT_STRIDE = 33;      // dwords per section in the octet table (33: bank-conflict-free)
-// LDS: 35 KiB of staged bytes covers 32 worst-case u32/f32 sections (1100 B) + the vector headers
-// between them; with the tables a workgroup stays under 40 KiB, so four workgroups share a CU's
-// 160 KiB.
-constexpr uint32_t LDS_DATA_BYTES = 35840;
-constexpr uint32_t LDS_DATA_PAD = 32;
+// Octet table: one 36-dword row per section (rows are 16-byte aligned so a lane fetches the four
+// octets it owns with one ds_read_b128).  Entries 0..31: LDS byte address of the octet (16 bits) |
+// nonzero mask (8) | nibble word (8).  Entries 32..35: per-section err, kind, LDS start, byte length.
+constexpr int OCT_STRIDE = 36;
+constexpr int ROW_ERR = 32, ROW_KIND = 33, ROW_REL = 34, ROW_LEN = 35;
+// LDS: the staged span covers 32 worst-case u32/f32 sections (1100 B) + the vector headers between
+// them + alignment; with the table a workgroup stays under 40 KiB, so four share a CU's 160 KiB.
+constexpr uint32_t LDS_DATA_BYTES = 35744;
+constexpr uint32_t LDS_DATA_PAD = 16;
 
-enum { MODE_FILTER = 0, MODE_DECODE = 1 };
+enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2 };
 
 struct SecShared {
     __attribute__((aligned(16))) uint8_t data[LDS_DATA_BYTES + LDS_DATA_PAD];
-    uint32_t octab[TILE * OCT_STRIDE];
+    __attribute__((aligned(16))) uint32_t octab[TILE * OCT_STRIDE];
     uint64_t off[TILE];
-    uint32_t len[TILE];  // bytes of the section the walk may touch (clipped to SectLimits)
-    uint32_t kind[TILE];
-    uint32_t err[TILE];
-    uint32_t rel[TILE];  // section start relative to the staged span
     int group_end;
 };
+
+// Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
+// LDS read here is a naturally aligned dword pair / triple that is then funnel-shifted.
+__device__ inline uint32_t lds_u16_at(const uint8_t *data, uint32_t p) {
+    const uint32_t *q = (const uint32_t *)(data + (p & ~3u));
+    return __builtin_amdgcn_alignbit(q[1], q[0], (p & 3u) << 3) & 0xffffu;
+}
 
 // One octet element: field `idx` (of width 4n bits) of the little-endian bitstream that follows the
 // two octet header bytes, shifted left by the trailing-zero nibbles; zero lanes give 0.  This is the
 // plain bitstream rule of the format (reference src/nibblepacking.rs:436-470,
 // src/nibblepack_simd.rs:571-585).
 template <int W>
-__device__ inline typename Elem<W>::U extract_elem(const uint8_t *sec, uint32_t d, uint32_t j, uint32_t jmask) {
-    const uint32_t rel = d & 0xffffu, mask = (d >> 16) & 0xffu, nw = d >> 24;
-    const uint32_t n4 = ((nw >> 4) + 1) << 2, tz = (nw & 15) << 2;
+__device__ inline typename Elem<W>::U extract_elem(const uint8_t *data, uint32_t d, uint32_t j, uint32_t jmask) {
+    const uint32_t addr = d & 0xffffu, mask = (d >> 16) & 0xffu;
+    const uint32_t n4 = ((d >> 28) << 2) + 4, tz = (d >> 22) & 0x3cu;
     const uint32_t idx = __popc(mask & jmask);
     const uint32_t bitpos = idx * n4;
-    const uint8_t *a = sec + rel + 2 + (bitpos >> 3);
-    const uint32_t sh = bitpos & 7; // 0 or 4
+    const uint32_t a = addr + 2 + (bitpos >> 3);
+    const uint32_t s = ((a & 3u) << 3) | (bitpos & 4u);        // bit offset inside the aligned dword
+    const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
+    const bool on = (mask >> j) & 1;
     if constexpr (W == 4) {
-        uint64_t w = *(const u64u *)a;
-        uint32_t x = (uint32_t)(w >> sh);
+        uint32_t x = __builtin_amdgcn_alignbit(q[1], q[0], s);
         x &= 0xffffffffu >> (32 - n4);
         x = (uint32_t)((uint64_t)x << tz); // a shift count >= 32 yields 0, as the AVX2 lane shift does
-        return ((mask >> j) & 1) ? x : 0u;
+        return on ? x : 0u;
     } else {
-        uint64_t w0 = *(const u64u *)a;
-        uint64_t w1 = a[8];
-        uint64_t x = sh ? ((w0 >> 4) | (w1 << 60)) : w0;
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, s) |
+                     ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, s) << 32);
         x &= ~0ull >> (64 - n4);
         x <<= tz;
-        return ((mask >> j) & 1) ? x : 0ull;
+        return on ? x : 0ull;
     }
 }
 
@@ -245,21 +252,27 @@ template <int W> __device__ inline typename Elem<W>::U shfl_up_t(typename Elem<W
     return __shfl_up(x, d, 64);
 }
 
-template <int ETYPE>
+template <int ETYPE, bool SINGLE>
 __device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CVEC_U64 ? 8 : 4)>::U x) {
-    bool m = false;
-    if constexpr (ETYPE == CVEC_F32) {
-        const float f = __uint_as_float((uint32_t)x);
-        for (uint32_t p = 0; p < pa.count; p++) m |= (f == __uint_as_float((uint32_t)pa.v[p])); // IEEE ==
-    } else if constexpr (ETYPE == CVEC_U32) {
-        for (uint32_t p = 0; p < pa.count; p++) m |= ((uint32_t)x == (uint32_t)pa.v[p]);
+    if constexpr (SINGLE) {
+        if constexpr (ETYPE == CVEC_F32) return __uint_as_float((uint32_t)x) == __uint_as_float((uint32_t)pa.v[0]);
+        else if constexpr (ETYPE == CVEC_U32) return (uint32_t)x == (uint32_t)pa.v[0];
+        else return x == pa.v[0];
     } else {
-        for (uint32_t p = 0; p < pa.count; p++) m |= (x == pa.v[p]);
+        bool m = false;
+        if constexpr (ETYPE == CVEC_F32) {
+            const float f = __uint_as_float((uint32_t)x);
+            for (uint32_t p = 0; p < pa.count; p++) m |= (f == __uint_as_float((uint32_t)pa.v[p])); // IEEE ==
+        } else if constexpr (ETYPE == CVEC_U32) {
+            for (uint32_t p = 0; p < pa.count; p++) m |= ((uint32_t)x == (uint32_t)pa.v[p]);
+        } else {
+            for (uint32_t p = 0; p < pa.count; p++) m |= (x == pa.v[p]);
+        }
+        return m;
     }
-    return m;
 }
 
-template <int ETYPE, int MODE>
+template <int ETYPE, int MODE, bool SINGLE>
 __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           PredArgs pa, SinkArgs sa, uint32_t *__restrict__ sec_res,
@@ -276,9 +289,10 @@ __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restr
         uint64_t d = tid < nsec ? desc[s0 + tid] : desc_pack(0, 0, K_SKIP);
         uint32_t len = desc_len(d);
         sm.off[tid] = desc_off(d);
-        sm.len[tid] = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
-        sm.kind[tid] = desc_kind(d);
-        sm.err[tid] = 0;
+        uint32_t *row = sm.octab + tid * OCT_STRIDE;
+        row[ROW_LEN] = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
+        row[ROW_KIND] = desc_kind(d);
+        row[ROW_ERR] = 0;
     }
     __syncthreads();
 
@@ -291,7 +305,8 @@ __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restr
         const uint64_t gbase = sm.off[i0] & ~15ull;
         if (wave == 0) {
             bool fits = lane < i0;
-            if (lane >= i0 && lane < nsec) fits = (sm.off[lane] + sm.len[lane] - gbase) <= (uint64_t)LDS_DATA_BYTES;
+            if (lane >= i0 && lane < nsec)
+                fits = (sm.off[lane] + sm.octab[lane * OCT_STRIDE + ROW_LEN] - gbase) <= (uint64_t)LDS_DATA_BYTES;
             unsigned long long m = __ballot(fits);
             int i1 = m == ~0ull ? 64 : __builtin_ctzll(~m);
             if (lane == 0) sm.group_end = i1 < nsec ? i1 : nsec;
@@ -300,32 +315,32 @@ __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restr
         const int i1 = sm.group_end;
         // ---- stage [gbase, end of section i1-1) with coalesced 16-byte loads -------------------------
         {
-            const uint32_t span = (uint32_t)(sm.off[i1 - 1] + sm.len[i1 - 1] - gbase);
+            const uint32_t span = (uint32_t)(sm.off[i1 - 1] + sm.octab[(i1 - 1) * OCT_STRIDE + ROW_LEN] - gbase);
             const uint32_t nchunks = (span + 15) >> 4;
             const uint4 *src = (const uint4 *)(bytes + gbase);
             uint4 *dst = (uint4 *)sm.data;
             for (uint32_t c = tid; c < nchunks; c += SEC_THREADS) dst[c] = src[c];
-            if (tid >= i0 && tid < i1) sm.rel[tid] = (uint32_t)(sm.off[tid] - gbase);
+            if (tid >= i0 && tid < i1) sm.octab[tid * OCT_STRIDE + ROW_REL] = (uint32_t)(sm.off[tid] - gbase);
         }
         __syncthreads();
         // ---- octet walk: one lane per section ----------------------------------------------------------
         if (tid >= i0 && tid < i1) {
-            const uint32_t kind = sm.kind[tid];
+            uint32_t *row = sm.octab + tid * OCT_STRIDE;
+            const uint32_t kind = row[ROW_KIND];
             if (kind == K_NP || kind == K_DELTA || kind == K_XOR) {
-                const uint32_t rel = sm.rel[tid];
-                const int end = (int)(rel + sm.len[tid]);
+                const uint32_t rel = row[ROW_REL];
+                const int end = (int)(rel + row[ROW_LEN]);
                 int p = (int)rel + (kind == K_DELTA ? DELTA_HDR : 3);
                 uint32_t err = 0;
                 for (int k = 0; k < FIXED_LEN / 8; k++) {
                     const int rem = end - p;
                     if (rem <= 0) { err = CVEC_NOT_ENOUGH_SPACE; break; }
-                    const uint32_t h = *(const u16u *)(sm.data + p);
+                    const uint32_t h = lds_u16_at(sm.data, (uint32_t)p);
                     const uint32_t mask = h & 0xffu;
-                    uint32_t entry = (uint32_t)(p - (int)rel);
+                    uint32_t entry = (uint32_t)p;
                     int size = 1;
                     if (mask) {
-                        const uint32_t nw = h >> 8;
-                        const uint32_t n = (nw >> 4) + 1;
+                        const uint32_t n = (h >> 12) + 1;
                         size = 2 + (int)((n * __popc(mask) + 1) >> 1);
                         if constexpr (W == 4) {
                             if (rem < 3) err = CVEC_NOT_ENOUGH_SPACE;
@@ -337,17 +352,20 @@ __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restr
                         if (err) break;
                         entry |= h << 16;
                     }
-                    sm.octab[tid * OCT_STRIDE + k] = entry;
+                    row[k] = entry;
                     p += size;
                 }
-                sm.err[tid] = err;
+                row[ROW_ERR] = err;
             }
         }
         __syncthreads();
         // ---- decode: each wave takes whole sections; lane (g, j) owns lane j of octets 4g..4g+3 ------
         for (int t = i0 + wave; t < i1; t += SEC_THREADS / 64) {
-            const uint32_t kind = __builtin_amdgcn_readfirstlane(sm.kind[t]);
-            const uint32_t err = __builtin_amdgcn_readfirstlane(sm.err[t]);
+            const uint32_t *row = sm.octab + t * OCT_STRIDE;
+            const uint4 meta = *(const uint4 *)(row + ROW_ERR);
+            const uint32_t err = __builtin_amdgcn_readfirstlane(meta.x);
+            const uint32_t kind = __builtin_amdgcn_readfirstlane(meta.y);
+            const uint32_t rel = __builtin_amdgcn_readfirstlane(meta.z);
             const uint64_t slot = s0 + t;
             uint32_t res;
             if (kind == K_SKIP) {
@@ -357,20 +375,27 @@ __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restr
             } else if (err) {
                 res = res_pack(0, err);
             } else {
-                const uint8_t *sec = sm.data + __builtin_amdgcn_readfirstlane(sm.rel[t]);
                 U x[4];
                 bool zeroes = false; // the section reaches the sink through process_zeroes()
                 if (kind == K_NULL) {
                     x[0] = x[1] = x[2] = x[3] = 0;
                     zeroes = true;
                 } else if (kind == K_CONST) {
+                    // value at section byte 1: aligned dwords + funnel shift
+                    const uint32_t a = rel + 1;
+                    const uint32_t *q = (const uint32_t *)(sm.data + (a & ~3u));
+                    const uint32_t s = (a & 3u) << 3;
                     U v;
-                    if constexpr (W == 4) v = *(const u32u *)(sec + 1); else v = *(const u64u *)(sec + 1);
+                    if constexpr (W == 4) v = __builtin_amdgcn_alignbit(q[1], q[0], s);
+                    else v = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
+                             ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
                     x[0] = x[1] = x[2] = x[3] = v;
                 } else {
-                    const uint32_t *tab = sm.octab + t * OCT_STRIDE + 4 * g;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) x[i] = extract_elem<W>(sec, tab[i], j, jmask);
+                    const uint4 tab = *(const uint4 *)(row + 4 * g);
+                    x[0] = extract_elem<W>(sm.data, tab.x, j, jmask);
+                    x[1] = extract_elem<W>(sm.data, tab.y, j, jmask);
+                    x[2] = extract_elem<W>(sm.data, tab.z, j, jmask);
+                    x[3] = extract_elem<W>(sm.data, tab.w, j, jmask);
                     if (ETYPE == CVEC_F32) {
                         // XorSink: out[k] = out[k-1] ^ x[k] per lane j, state zero at the section start
                         // (src/sink.rs:271-275, src/section.rs:707): serial over the lane's 4 octets,
@@ -385,25 +410,31 @@ __global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restr
                         x[0] ^= excl; x[1] ^= excl; x[2] ^= excl; x[3] ^= excl;
                     } else if (kind == K_DELTA) {
                         // AddConstSink(base) around the octet decode (src/section.rs:636-641), wrapping
+                        const uint32_t a = rel + 4;
+                        const uint32_t *q = (const uint32_t *)(sm.data + (a & ~3u));
+                        const uint32_t s = (a & 3u) << 3;
                         U base;
-                        if constexpr (W == 4) base = *(const u32u *)(sec + 4); else base = *(const u64u *)(sec + 4);
+                        if constexpr (W == 4) base = __builtin_amdgcn_alignbit(q[1], q[0], s);
+                        else base = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
+                                    ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
                         x[0] += base; x[1] += base; x[2] += base; x[3] += base;
                     }
                 }
-                if constexpr (MODE == MODE_FILTER) {
+                if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
                     uint32_t cnt = 0;
                     if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
                         cnt = pa.match_zero ? FIXED_LEN : 0;
-                        if (masks && lane < 8) ((uint32_t *)(masks + slot * 32))[lane] = pa.match_zero ? ~0u : 0u;
+                        if (MODE == MODE_FILTER_MASKS && lane < 8)
+                            ((uint32_t *)(masks + slot * 32))[lane] = pa.match_zero ? ~0u : 0u;
                     } else {
                         uint32_t mword = 0;
 #pragma unroll
                         for (int i = 0; i < 4; i++) {
-                            unsigned long long b = __ballot(pred_match<ETYPE>(pa, x[i]));
+                            unsigned long long b = __ballot(pred_match<ETYPE, SINGLE>(pa, x[i]));
                             cnt += __popcll(b);
-                            mword |= (uint32_t)((b >> (8 * g)) & 0xffu) << (8 * i);
+                            if (MODE == MODE_FILTER_MASKS) mword |= (uint32_t)((b >> (8 * g)) & 0xffu) << (8 * i);
                         }
-                        if (masks && j == 0) ((uint32_t *)(masks + slot * 32))[g] = mword;
+                        if (MODE == MODE_FILTER_MASKS && j == 0) ((uint32_t *)(masks + slot * 32))[g] = mword;
                     }
                     res = res_pack(cnt, 0);
                 } else {
@@ -569,12 +600,13 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
     timer_mark(rec, 2, stream);
     if (ns > 0) {
         const uint32_t ntiles = (uint32_t)((ns + TILE - 1) / TILE);
-        if (mode == MODE_FILTER)
-            k_sections<ETYPE, MODE_FILTER><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res,
-                                                                               d_masks, nullptr);
-        else
-            k_sections<ETYPE, MODE_DECODE><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res,
-                                                                               nullptr, d_out);
+        const bool single = pa.count == 1;
+#define CVEC_LAUNCH_SEC(M, S)                                                                                       \
+    k_sections<ETYPE, M, S><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out)
+        if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);
+        else if (d_masks) { if (single) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, true); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, false); }
+        else { if (single) CVEC_LAUNCH_SEC(MODE_FILTER, true); else CVEC_LAUNCH_SEC(MODE_FILTER, false); }
+#undef CVEC_LAUNCH_SEC
     }
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
