@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcvec_hip.so")
+LIB_PATH = os.environ.get("CVEC_LIB_PATH") or os.path.join(_HERE, "lib", "libcvec_hip.so")
 
 U64, U32, F32 = 0x10, 0x11, 0x12
 PRED_EQ, PRED_ONEOF = 0, 1

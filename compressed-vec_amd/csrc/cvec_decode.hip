@@ -13,6 +13,8 @@
 //               per lane, undoes XOR with a wavefront scan and either compares (filter) or stores.
 //   k_finalize  one lane per vector folds its sections' results in order, so a failing section
 //               ends that vector exactly where the reference's iteration would stop.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "cvec_device.hpp"
@@ -192,7 +194,6 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
 // k_sections
 // ------------------------------------------------------------------------------------------------
 constexpr int TILE = 32;            // section slots per workgroup
-constexpr int SEC_THREADS = 256;    // 4 waves
 // Octet table: one 36-dword row per section (rows are 16-byte aligned so a lane fetches the four
 // octets it owns with one ds_read_b128).  Entries 0..31: LDS byte address of the octet (16 bits) |
 // nonzero mask (8) | nibble word (8).  Entries 32..35: per-section err, kind, LDS start, byte length.
@@ -205,11 +206,24 @@ constexpr uint32_t LDS_DATA_PAD = 16;
 
 enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2 };
 
+constexpr int SEC_THREADS = 512;                      // wave 0 walks, waves 1..7 decode
+constexpr int N_DECODE_WAVES = SEC_THREADS / 64 - 1;
+constexpr int STAGE_IT = (LDS_DATA_BYTES / 16 + SEC_THREADS - 1) / SEC_THREADS;
+
+// A chunk = up to TILE consecutive section slots whose bytes fit one staging buffer as one span.
+struct ChunkParams {
+    uint64_t s0;      // first section slot
+    uint64_t gbase;   // 16-byte aligned blob offset of the span
+    uint32_t n;       // sections in the chunk (0 = no such chunk)
+    uint32_t nchunks; // 16-byte pieces of the span
+};
+
+// Two staging buffers + two octet tables: while chunk c is decoded out of one pair, chunk c+1 is
+// walked in the other.  80.8 KB per workgroup, so two workgroups share a CU's 160 KiB.
 struct SecShared {
-    __attribute__((aligned(16))) uint8_t data[LDS_DATA_BYTES + LDS_DATA_PAD];
-    __attribute__((aligned(16))) uint32_t octab[TILE * OCT_STRIDE];
-    uint64_t off[TILE];
-    int group_end;
+    __attribute__((aligned(16))) uint8_t data[2][LDS_DATA_BYTES + LDS_DATA_PAD];
+    __attribute__((aligned(16))) uint32_t octab[2][TILE * OCT_STRIDE];
+    ChunkParams P[4];
 };
 
 // Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
@@ -272,195 +286,278 @@ __device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CV
     }
 }
 
+// Decodes section `sec` of a chunk (whole wave): lane (g, j) owns lane j of octets 4g..4g+3, i.e.
+// 4 elements, runs them through the implied XorSink / Delta add and the fused epilogue.
 template <int ETYPE, int MODE, bool SINGLE>
-__global__ __launch_bounds__(SEC_THREADS) void k_sections(const uint8_t *__restrict__ bytes,
-                                                          const uint64_t *__restrict__ desc, uint64_t n_sections,
-                                                          PredArgs pa, SinkArgs sa, uint32_t *__restrict__ sec_res,
-                                                          uint8_t *__restrict__ masks, void *__restrict__ out_) {
+__device__ inline void decode_section(const uint8_t *data, const uint32_t *row, uint64_t slot, int lane,
+                                      const PredArgs &pa, const SinkArgs &sa, uint32_t *__restrict__ sec_res,
+                                      uint8_t *__restrict__ masks, void *__restrict__ out_) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
+    const uint32_t g = lane >> 3, j = lane & 7, jmask = (1u << j) - 1u;
+    const uint4 meta = *(const uint4 *)(row + ROW_ERR);
+    const uint32_t err = __builtin_amdgcn_readfirstlane(meta.x);
+    const uint32_t kind = __builtin_amdgcn_readfirstlane(meta.y);
+    const uint32_t rel = __builtin_amdgcn_readfirstlane(meta.z);
+    uint32_t res;
+    if (kind == K_SKIP) {
+        res = res_pack(0, 0);
+    } else if (kind == K_ILLEGAL) {
+        res = res_pack(0, CVEC_INVALID_FORMAT);
+    } else if (err) {
+        res = res_pack(0, err);
+    } else {
+        U x[4];
+        bool zeroes = false; // the section reaches the sink through process_zeroes()
+        if (kind == K_NULL) {
+            x[0] = x[1] = x[2] = x[3] = 0;
+            zeroes = true;
+        } else if (kind == K_CONST) {
+            // value at section byte 1: aligned dwords + funnel shift
+            const uint32_t a = rel + 1;
+            const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
+            const uint32_t s = (a & 3u) << 3;
+            U v;
+            if constexpr (W == 4) v = __builtin_amdgcn_alignbit(q[1], q[0], s);
+            else v = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
+                     ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
+            x[0] = x[1] = x[2] = x[3] = v;
+        } else {
+            const uint4 tab = *(const uint4 *)(row + 4 * g);
+            x[0] = extract_elem<W>(data, tab.x, j, jmask);
+            x[1] = extract_elem<W>(data, tab.y, j, jmask);
+            x[2] = extract_elem<W>(data, tab.z, j, jmask);
+            x[3] = extract_elem<W>(data, tab.w, j, jmask);
+            if (ETYPE == CVEC_F32) {
+                // XorSink: out[k] = out[k-1] ^ x[k] per lane j, state zero at the section start
+                // (src/sink.rs:271-275, src/section.rs:707): serial over the lane's 4 octets, then an
+                // exclusive scan over the 8 octet groups (lane strides 8, 16, 32).
+                x[1] ^= x[0]; x[2] ^= x[1]; x[3] ^= x[2];
+                U tot = x[3];
+                U y = shfl_up_t<W>(tot, 8);  if (g >= 1) tot ^= y;
+                y = shfl_up_t<W>(tot, 16);   if (g >= 2) tot ^= y;
+                y = shfl_up_t<W>(tot, 32);   if (g >= 4) tot ^= y;
+                U excl = shfl_up_t<W>(tot, 8);
+                if (g == 0) excl = 0;
+                x[0] ^= excl; x[1] ^= excl; x[2] ^= excl; x[3] ^= excl;
+            } else if (kind == K_DELTA) {
+                // AddConstSink(base) around the octet decode (src/section.rs:636-641), wrapping
+                const uint32_t a = rel + 4;
+                const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
+                const uint32_t s = (a & 3u) << 3;
+                U base;
+                if constexpr (W == 4) base = __builtin_amdgcn_alignbit(q[1], q[0], s);
+                else base = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
+                            ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
+                x[0] += base; x[1] += base; x[2] += base; x[3] += base;
+            }
+        }
+        if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
+            uint32_t cnt = 0;
+            if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
+                cnt = pa.match_zero ? FIXED_LEN : 0;
+                if (MODE == MODE_FILTER_MASKS && lane < 8)
+                    ((uint32_t *)(masks + slot * 32))[lane] = pa.match_zero ? ~0u : 0u;
+            } else {
+                uint32_t mword = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    unsigned long long b = __ballot(pred_match<ETYPE, SINGLE>(pa, x[i]));
+                    cnt += __popcll(b);
+                    if (MODE == MODE_FILTER_MASKS) mword |= (uint32_t)((b >> (8 * g)) & 0xffu) << (8 * i);
+                }
+                if (MODE == MODE_FILTER_MASKS && j == 0) ((uint32_t *)(masks + slot * 32))[g] = mword;
+            }
+            res = res_pack(cnt, 0);
+        } else {
+            if (sa.add_const) {
+                // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards the
+                // base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
+                if constexpr (ETYPE == CVEC_F32) {
+                    const float b = __uint_as_float((uint32_t)sa.base);
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        x[i] = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x[i]) + b);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) x[i] += (U)sa.base;
+                }
+            }
+            U *o = (U *)out_ + slot * FIXED_LEN + 32 * g + j;
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[8 * i] = x[i];
+            res = res_pack(FIXED_LEN, 0);
+        }
+    }
+    if (lane == 0) sec_res[slot] = res;
+}
+
+// The octet walk of one section by one lane: 32 dependent steps, each one LDS round trip (two byte
+// reads, always aligned) plus a short chain popc -> mad -> shift -> select -> add, branch-free and
+// with as few instructions beside the chain as possible (a lone wave issues one VALU op per ~4
+// cycles, so every extra instruction per step is paid 32 times on the critical path).  The loop
+// only remembers the first suspicious octet; its exact status is worked out afterwards.  After an
+// error the cursor keeps moving over garbage (reads stay inside the workgroup's LDS allocation or
+// return 0); the sticky error decides the section's result.
+template <int W>
+__device__ inline void walk_section(const uint8_t *data, uint32_t *row) {
+    const uint32_t kind = row[ROW_KIND];
+    if (!(kind == K_NP || kind == K_DELTA || kind == K_XOR)) return;
+    const uint32_t rel = row[ROW_REL];
+    const int end = (int)(rel + row[ROW_LEN]);
+    int p = (int)rel + (kind == K_DELTA ? DELTA_HDR : 3);
+    int kbad = FIXED_LEN / 8;
+#pragma unroll 4
+    for (int k = 0; k < FIXED_LEN / 8; k++) {
+        const uint32_t mask = data[p];
+        const uint32_t nw = data[p + 1];
+        const uint32_t hn = nw >> 4; // n - 1
+        const uint32_t cnt = __popc(mask);
+        const int size = mask ? (int)((hn * cnt + cnt + 5) >> 1) : 1; // 2 + (n*cnt + 1) / 2
+        // size > remaining covers every NotEnoughSpace case (an all-zero octet has size 1)
+        bool bad = p + size > end;
+        if constexpr (W == 4) bad |= (hn > 7) & (mask != 0);
+        kbad = (bad && kbad == FIXED_LEN / 8) ? k : kbad;
+        row[k] = (uint32_t)p | (mask << 16) | (nw << 24); // nw is don't-care when mask == 0
+        p += size;
+    }
+    uint32_t err = 0;
+    if (kbad < FIXED_LEN / 8) {
+        // exact status of the first failing octet, in the order of the reference's checks
+        // (src/nibblepack_simd.rs:515-557): empty, length < 3, n > 8, payload
+        const uint32_t e = row[kbad];
+        const int pk = (int)(e & 0xffffu), rem = end - pk;
+        const uint32_t mask = (e >> 16) & 0xffu, hn = e >> 28;
+        err = CVEC_NOT_ENOUGH_SPACE;
+        if (W == 4 && rem >= 3 && mask != 0 && hn > 7) err = CVEC_INVALID_FORMAT;
+    }
+    row[ROW_ERR] = err;
+}
+
+// k_sections: persistent workgroups, each owning a contiguous range of section slots, run a
+// four-stage software pipeline over chunks of that range.  In step t:
+//     wave 0            computes the extent of chunk t from its descriptors, then walks chunk t-2
+//     waves 1..7        decode chunk t-3                                   (other LDS buffer pair)
+//   -- barrier --
+//     all waves         write chunk t-1 (held in registers) into the buffer chunk t-3 just vacated,
+//                       then issue the global loads of chunk t into registers
+//   -- barrier --
+// so the HBM latency of a chunk is hidden behind a whole step, the serial octet walk of one chunk
+// runs beside the decode of another, and the blob is streamed at a steady rate.
+template <int ETYPE, int MODE, bool SINGLE>
+__global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__restrict__ bytes,
+                                                          const uint64_t *__restrict__ desc, uint64_t n_sections,
+                                                          uint64_t sections_per_wg, PredArgs pa, SinkArgs sa,
+                                                          uint32_t *__restrict__ sec_res,
+                                                          uint8_t *__restrict__ masks, void *__restrict__ out_) {
+    constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared sm;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t s0 = (uint64_t)blockIdx.x * TILE;
-    const int nsec = (int)((n_sections - s0) < (uint64_t)TILE ? (n_sections - s0) : (uint64_t)TILE);
+    const uint64_t sA = (uint64_t)blockIdx.x * sections_per_wg;
+    const uint64_t sB = sA + sections_per_wg < n_sections ? sA + sections_per_wg : n_sections;
+    if (sA >= sB) return;
 
-    if (tid < TILE) {
-        uint64_t d = tid < nsec ? desc[s0 + tid] : desc_pack(0, 0, K_SKIP);
-        uint32_t len = desc_len(d);
-        sm.off[tid] = desc_off(d);
-        uint32_t *row = sm.octab + tid * OCT_STRIDE;
-        row[ROW_LEN] = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
-        row[ROW_KIND] = desc_kind(d);
-        row[ROW_ERR] = 0;
-    }
-    __syncthreads();
+    // control state, meaningful in wave 0 only (lanes 0..TILE-1 hold one descriptor each)
+    auto load_desc = [&](uint64_t s) -> uint64_t {
+        return (lane < TILE && s + (uint64_t)lane < sB) ? desc[s + lane] : desc_pack(0, 0, K_SKIP);
+    };
+    auto clip_len = [](uint64_t d) -> uint32_t {
+        const uint32_t len = desc_len(d);
+        return len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
+    };
+    uint64_t d_prev = desc_pack(0, 0, K_SKIP), d_cur = desc_pack(0, 0, K_SKIP);
+    uint64_t s_cur = sA, gbase_prev = 0;
+    uint32_t n_prev = 0;
+    if (wave == 0) d_cur = load_desc(sA);
 
-    const uint32_t g = lane >> 3, j = lane & 7, jmask = (1u << j) - 1u;
-    U *out = (U *)out_;
+    uint4 R[STAGE_IT];
+#pragma unroll
+    for (int it = 0; it < STAGE_IT; it++) R[it] = make_uint4(0, 0, 0, 0);
+    uint32_t r_nchunks = 0;
 
-    int i0 = 0;
-    while (i0 < nsec) {
-        // ---- group = longest run of sections from i0 whose bytes fit the staging buffer ----------
-        const uint64_t gbase = sm.off[i0] & ~15ull;
+    for (uint32_t t = 0;; t++) {
         if (wave == 0) {
-            bool fits = lane < i0;
-            if (lane >= i0 && lane < nsec)
-                fits = (sm.off[lane] + sm.octab[lane * OCT_STRIDE + ROW_LEN] - gbase) <= (uint64_t)LDS_DATA_BYTES;
-            unsigned long long m = __ballot(fits);
-            int i1 = m == ~0ull ? 64 : __builtin_ctzll(~m);
-            if (lane == 0) sm.group_end = i1 < nsec ? i1 : nsec;
+            // ---- extent of chunk t: longest run of sections from s_cur whose span fits a buffer -----
+            const uint64_t left = s_cur < sB ? sB - s_cur : 0;
+            const int avail = (int)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
+            const uint64_t off = desc_off(d_cur);
+            const uint64_t gb = __shfl(off, 0, 64) & ~15ull;
+            const uint64_t endl = off + clip_len(d_cur) - gb; // wraps to a huge value if off < gb
+            const bool fits = lane >= avail || endl <= (uint64_t)LDS_DATA_BYTES;
+            const unsigned long long m = __ballot(fits);
+            int n = m == ~0ull ? avail : __builtin_ctzll(~m);
+            n = n < avail ? n : avail;
+            uint32_t e = lane < n ? (uint32_t)endl : 0u;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(e, d, 64); e = o > e ? o : e; }
+            if (lane == 0) {
+                ChunkParams cp;
+                cp.s0 = s_cur; cp.gbase = gb; cp.n = (uint32_t)n; cp.nchunks = (e + 15) >> 4;
+                sm.P[t & 3] = cp;
+            }
+            // descriptors of chunk t+1 start where chunk t ends
+            const uint64_t s_next = s_cur + (uint64_t)n;
+            const uint64_t d_next = load_desc(s_next);
+            // ---- walk chunk t-2 -----------------------------------------------------------------------
+            if (t >= 2 && sa._pad != 1) {
+                const uint32_t nw = sm.P[(t - 2) & 3].n;
+                if ((uint32_t)lane < nw) {
+                    __builtin_amdgcn_s_setprio(3); // seven waves will wait on this chain at the barrier
+                    walk_section<W>(sm.data[t & 1], sm.octab[t & 1] + lane * OCT_STRIDE);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+            }
+            // ---- barrier X ----
+            __syncthreads();
+            if (t >= 1 && (uint32_t)lane < n_prev) {
+                uint32_t *row = sm.octab[(t - 1) & 1] + lane * OCT_STRIDE;
+                row[ROW_LEN] = clip_len(d_prev);
+                row[ROW_KIND] = desc_kind(d_prev);
+                row[ROW_REL] = (uint32_t)(desc_off(d_prev) - gbase_prev);
+                row[ROW_ERR] = 0;
+            }
+            // shift the descriptor window: next step writes the table rows of chunk t from d_prev
+            d_prev = d_cur; d_cur = d_next;
+            gbase_prev = gb; n_prev = (uint32_t)n; s_cur = s_next;
+        } else {
+            // ---- decode chunk t-3 ------------------------------------------------------------------------
+            if (t >= 3 && sa._pad == 0) {
+                const ChunkParams cp = sm.P[(t - 3) & 3];
+                const uint32_t nd = __builtin_amdgcn_readfirstlane(cp.n);
+                for (uint32_t sec = (uint32_t)wave - 1; sec < nd; sec += N_DECODE_WAVES)
+                    decode_section<ETYPE, MODE, SINGLE>(sm.data[(t - 3) & 1],
+                                                        sm.octab[(t - 3) & 1] + sec * OCT_STRIDE, cp.s0 + sec, lane,
+                                                        pa, sa, sec_res, masks, out_);
+            }
+            // ---- barrier X ----
+            __syncthreads();
         }
-        __syncthreads();
-        const int i1 = sm.group_end;
-        // ---- stage [gbase, end of section i1-1) with coalesced 16-byte loads -------------------------
+        // ---- write chunk t-1 (registers -> the buffer chunk t-3 vacated), issue the loads of chunk t -----
+        if (t >= 1) {
+            uint4 *dst = (uint4 *)sm.data[(t - 1) & 1];
+#pragma unroll
+            for (int it = 0; it < STAGE_IT; it++) {
+                const uint32_t c = tid + it * SEC_THREADS;
+                if (c < r_nchunks) dst[c] = R[it];
+            }
+        }
         {
-            const uint32_t span = (uint32_t)(sm.off[i1 - 1] + sm.octab[(i1 - 1) * OCT_STRIDE + ROW_LEN] - gbase);
-            const uint32_t nchunks = (span + 15) >> 4;
-            const uint4 *src = (const uint4 *)(bytes + gbase);
-            uint4 *dst = (uint4 *)sm.data;
-            for (uint32_t c = tid; c < nchunks; c += SEC_THREADS) dst[c] = src[c];
-            if (tid >= i0 && tid < i1) sm.octab[tid * OCT_STRIDE + ROW_REL] = (uint32_t)(sm.off[tid] - gbase);
-        }
-        __syncthreads();
-        // ---- octet walk: one lane per section ----------------------------------------------------------
-        if (tid >= i0 && tid < i1) {
-            uint32_t *row = sm.octab + tid * OCT_STRIDE;
-            const uint32_t kind = row[ROW_KIND];
-            if (kind == K_NP || kind == K_DELTA || kind == K_XOR) {
-                const uint32_t rel = row[ROW_REL];
-                const int end = (int)(rel + row[ROW_LEN]);
-                int p = (int)rel + (kind == K_DELTA ? DELTA_HDR : 3);
-                uint32_t err = 0;
-                for (int k = 0; k < FIXED_LEN / 8; k++) {
-                    const int rem = end - p;
-                    if (rem <= 0) { err = CVEC_NOT_ENOUGH_SPACE; break; }
-                    const uint32_t h = lds_u16_at(sm.data, (uint32_t)p);
-                    const uint32_t mask = h & 0xffu;
-                    uint32_t entry = (uint32_t)p;
-                    int size = 1;
-                    if (mask) {
-                        const uint32_t n = (h >> 12) + 1;
-                        size = 2 + (int)((n * __popc(mask) + 1) >> 1);
-                        if constexpr (W == 4) {
-                            if (rem < 3) err = CVEC_NOT_ENOUGH_SPACE;
-                            else if (n > 8) err = CVEC_INVALID_FORMAT;
-                            else if (size > rem) err = CVEC_NOT_ENOUGH_SPACE;
-                        } else {
-                            if (rem < 2 || size > rem) err = CVEC_NOT_ENOUGH_SPACE;
-                        }
-                        if (err) break;
-                        entry |= h << 16;
-                    }
-                    row[k] = entry;
-                    p += size;
-                }
-                row[ROW_ERR] = err;
-            }
-        }
-        __syncthreads();
-        // ---- decode: each wave takes whole sections; lane (g, j) owns lane j of octets 4g..4g+3 ------
-        for (int t = i0 + wave; t < i1; t += SEC_THREADS / 64) {
-            const uint32_t *row = sm.octab + t * OCT_STRIDE;
-            const uint4 meta = *(const uint4 *)(row + ROW_ERR);
-            const uint32_t err = __builtin_amdgcn_readfirstlane(meta.x);
-            const uint32_t kind = __builtin_amdgcn_readfirstlane(meta.y);
-            const uint32_t rel = __builtin_amdgcn_readfirstlane(meta.z);
-            const uint64_t slot = s0 + t;
-            uint32_t res;
-            if (kind == K_SKIP) {
-                res = res_pack(0, 0);
-            } else if (kind == K_ILLEGAL) {
-                res = res_pack(0, CVEC_INVALID_FORMAT);
-            } else if (err) {
-                res = res_pack(0, err);
-            } else {
-                U x[4];
-                bool zeroes = false; // the section reaches the sink through process_zeroes()
-                if (kind == K_NULL) {
-                    x[0] = x[1] = x[2] = x[3] = 0;
-                    zeroes = true;
-                } else if (kind == K_CONST) {
-                    // value at section byte 1: aligned dwords + funnel shift
-                    const uint32_t a = rel + 1;
-                    const uint32_t *q = (const uint32_t *)(sm.data + (a & ~3u));
-                    const uint32_t s = (a & 3u) << 3;
-                    U v;
-                    if constexpr (W == 4) v = __builtin_amdgcn_alignbit(q[1], q[0], s);
-                    else v = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
-                             ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
-                    x[0] = x[1] = x[2] = x[3] = v;
-                } else {
-                    const uint4 tab = *(const uint4 *)(row + 4 * g);
-                    x[0] = extract_elem<W>(sm.data, tab.x, j, jmask);
-                    x[1] = extract_elem<W>(sm.data, tab.y, j, jmask);
-                    x[2] = extract_elem<W>(sm.data, tab.z, j, jmask);
-                    x[3] = extract_elem<W>(sm.data, tab.w, j, jmask);
-                    if (ETYPE == CVEC_F32) {
-                        // XorSink: out[k] = out[k-1] ^ x[k] per lane j, state zero at the section start
-                        // (src/sink.rs:271-275, src/section.rs:707): serial over the lane's 4 octets,
-                        // then an exclusive scan over the 8 octet groups (lane strides 8, 16, 32).
-                        x[1] ^= x[0]; x[2] ^= x[1]; x[3] ^= x[2];
-                        U tot = x[3];
-                        U y = shfl_up_t<W>(tot, 8);  if (g >= 1) tot ^= y;
-                        y = shfl_up_t<W>(tot, 16);   if (g >= 2) tot ^= y;
-                        y = shfl_up_t<W>(tot, 32);   if (g >= 4) tot ^= y;
-                        U excl = shfl_up_t<W>(tot, 8);
-                        if (g == 0) excl = 0;
-                        x[0] ^= excl; x[1] ^= excl; x[2] ^= excl; x[3] ^= excl;
-                    } else if (kind == K_DELTA) {
-                        // AddConstSink(base) around the octet decode (src/section.rs:636-641), wrapping
-                        const uint32_t a = rel + 4;
-                        const uint32_t *q = (const uint32_t *)(sm.data + (a & ~3u));
-                        const uint32_t s = (a & 3u) << 3;
-                        U base;
-                        if constexpr (W == 4) base = __builtin_amdgcn_alignbit(q[1], q[0], s);
-                        else base = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
-                                    ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
-                        x[0] += base; x[1] += base; x[2] += base; x[3] += base;
-                    }
-                }
-                if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
-                    uint32_t cnt = 0;
-                    if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
-                        cnt = pa.match_zero ? FIXED_LEN : 0;
-                        if (MODE == MODE_FILTER_MASKS && lane < 8)
-                            ((uint32_t *)(masks + slot * 32))[lane] = pa.match_zero ? ~0u : 0u;
-                    } else {
-                        uint32_t mword = 0;
+            const ChunkParams cp = sm.P[t & 3];
+            const uint32_t nch = __builtin_amdgcn_readfirstlane(cp.n) ? __builtin_amdgcn_readfirstlane(cp.nchunks) : 0u;
+            r_nchunks = nch;
+            if (nch) {
+                const uint4 *src = (const uint4 *)(bytes + cp.gbase);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            unsigned long long b = __ballot(pred_match<ETYPE, SINGLE>(pa, x[i]));
-                            cnt += __popcll(b);
-                            if (MODE == MODE_FILTER_MASKS) mword |= (uint32_t)((b >> (8 * g)) & 0xffu) << (8 * i);
-                        }
-                        if (MODE == MODE_FILTER_MASKS && j == 0) ((uint32_t *)(masks + slot * 32))[g] = mword;
-                    }
-                    res = res_pack(cnt, 0);
-                } else {
-                    if (sa.add_const) {
-                        // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards
-                        // the base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
-                        if constexpr (ETYPE == CVEC_F32) {
-                            const float b = __uint_as_float((uint32_t)sa.base);
-#pragma unroll
-                            for (int i = 0; i < 4; i++)
-                                x[i] = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x[i]) + b);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 4; i++) x[i] += (U)sa.base;
-                        }
-                    }
-                    U *o = out + slot * FIXED_LEN + 32 * g + j;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[8 * i] = x[i];
-                    res = res_pack(FIXED_LEN, 0);
+                for (int it = 0; it < STAGE_IT; it++) {
+                    const uint32_t c = tid + it * SEC_THREADS;
+                    R[it] = src[c < nch ? c : 0u]; // lanes past the span re-read piece 0 (cheap, keeps R in registers)
                 }
             }
-            if (lane == 0) sec_res[slot] = res;
         }
+        // ---- barrier Y ----
         __syncthreads();
-        i0 = i1;
+        if (t >= 2 && sm.P[(t - 2) & 3].n == 0) break; // chunk t-2 does not exist: nothing left in flight
     }
 }
 
@@ -599,10 +696,18 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (ns > 0) {
-        const uint32_t ntiles = (uint32_t)((ns + TILE - 1) / TILE);
+        // Persistent workgroups: two fit a CU (LDS), so 2 x 256 x 2 rounds; each owns a contiguous
+        // range of section slots (a multiple of TILE) and pipelines over it.
+        uint64_t per = (ns + 1023) / 1024;
+        per = (per + TILE - 1) / TILE * TILE;
+        if (per < 4 * TILE) per = 4 * TILE;
+        const uint32_t nwg = (uint32_t)((ns + per - 1) / per);
         const bool single = pa.count == 1;
+        static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
+        SinkArgs sa2 = sa;
+        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage only, 2 = stage + walk
 #define CVEC_LAUNCH_SEC(M, S)                                                                                       \
-    k_sections<ETYPE, M, S><<<ntiles, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out)
+    k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
         if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);
         else if (d_masks) { if (single) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, true); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, false); }
         else { if (single) CVEC_LAUNCH_SEC(MODE_FILTER, true); else CVEC_LAUNCH_SEC(MODE_FILTER, false); }
