@@ -262,6 +262,23 @@ __device__ inline typename Elem<W>::U extract_elem(const uint8_t *data, uint32_t
     }
 }
 
+// Exclusive XOR scan over the 8 octet groups of a wave (group g = lanes 8g..8g+7, same j = lane & 7):
+// returns XOR of `tot` of the groups before this lane's group.  Pure cross-lane VALU (DPP inside a
+// 16-lane row, v_permlane16_swap between rows, v_permlane32_swap between halves): no LDS round trips.
+__device__ inline uint32_t xor_excl_over_groups(uint32_t tot, int lane) {
+    // odd group of a row <- the even group's value (lanes 0-7 of a row get 0)
+    const uint32_t y = __builtin_amdgcn_update_dpp(0u, tot, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    const uint32_t t1 = tot ^ y; // odd groups: total of the row's pair
+    // every lane of row r <- the pair total of row r (for its j)
+    const uint32_t pt = __builtin_amdgcn_update_dpp(t1, t1, 0x128 /* row_ror:8 */, 0xf, 0x3, false);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(pt, pt, false, false); // [pt0,pt0,pt2,pt2], [pt1,pt1,pt3,pt3]
+    const uint32_t prev_row = (lane & 16) ? s16[0] : 0u;                      // odd rows: the even row before them
+    const uint32_t q = s16[0] ^ s16[1];                                       // total of the 32-lane half
+    const auto s32 = __builtin_amdgcn_permlane32_swap(q, q, false, false);    // [q.lo, q.lo], [q.hi, q.hi]
+    const uint32_t prev_half = (lane & 32) ? s32[0] : 0u;
+    return y ^ prev_row ^ prev_half;
+}
+
 template <int W> __device__ inline typename Elem<W>::U shfl_up_t(typename Elem<W>::U x, int d) {
     return __shfl_up(x, d, 64);
 }
@@ -296,6 +313,7 @@ __device__ inline void decode_section(const uint8_t *data, const uint32_t *row, 
     using U = typename Elem<W>::U;
     const uint32_t g = lane >> 3, j = lane & 7, jmask = (1u << j) - 1u;
     const uint4 meta = *(const uint4 *)(row + ROW_ERR);
+    const uint4 tab = *(const uint4 *)(row + 4 * g); // issued with the meta read: one LDS round trip
     const uint32_t err = __builtin_amdgcn_readfirstlane(meta.x);
     const uint32_t kind = __builtin_amdgcn_readfirstlane(meta.y);
     const uint32_t rel = __builtin_amdgcn_readfirstlane(meta.z);
@@ -323,7 +341,6 @@ __device__ inline void decode_section(const uint8_t *data, const uint32_t *row, 
                      ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
             x[0] = x[1] = x[2] = x[3] = v;
         } else {
-            const uint4 tab = *(const uint4 *)(row + 4 * g);
             x[0] = extract_elem<W>(data, tab.x, j, jmask);
             x[1] = extract_elem<W>(data, tab.y, j, jmask);
             x[2] = extract_elem<W>(data, tab.z, j, jmask);
@@ -331,14 +348,9 @@ __device__ inline void decode_section(const uint8_t *data, const uint32_t *row, 
             if (ETYPE == CVEC_F32) {
                 // XorSink: out[k] = out[k-1] ^ x[k] per lane j, state zero at the section start
                 // (src/sink.rs:271-275, src/section.rs:707): serial over the lane's 4 octets, then an
-                // exclusive scan over the 8 octet groups (lane strides 8, 16, 32).
+                // exclusive scan over the 8 octet groups (lane strides 8, 16, 32), all in registers.
                 x[1] ^= x[0]; x[2] ^= x[1]; x[3] ^= x[2];
-                U tot = x[3];
-                U y = shfl_up_t<W>(tot, 8);  if (g >= 1) tot ^= y;
-                y = shfl_up_t<W>(tot, 16);   if (g >= 2) tot ^= y;
-                y = shfl_up_t<W>(tot, 32);   if (g >= 4) tot ^= y;
-                U excl = shfl_up_t<W>(tot, 8);
-                if (g == 0) excl = 0;
+                const uint32_t excl = xor_excl_over_groups((uint32_t)x[3], lane);
                 x[0] ^= excl; x[1] ^= excl; x[2] ^= excl; x[3] ^= excl;
             } else if (kind == K_DELTA) {
                 // AddConstSink(base) around the octet decode (src/section.rs:636-641), wrapping
@@ -404,32 +416,47 @@ __device__ inline void walk_section(const uint8_t *data, uint32_t *row) {
     const uint32_t kind = row[ROW_KIND];
     if (!(kind == K_NP || kind == K_DELTA || kind == K_XOR)) return;
     const uint32_t rel = row[ROW_REL];
-    const int end = (int)(rel + row[ROW_LEN]);
-    int p = (int)rel + (kind == K_DELTA ? DELTA_HDR : 3);
-    int kbad = FIXED_LEN / 8;
-#pragma unroll 4
+    const uint32_t end = rel + row[ROW_LEN];
+    uint32_t p = rel + (kind == K_DELTA ? DELTA_HDR : 3);
+    // same cursor as a raw LDS byte address, advanced beside p (not behind it)
+    uint32_t pa = (uint32_t)(uintptr_t)data + p;
+    uint32_t hnmax = 0;
+#pragma unroll 8
     for (int k = 0; k < FIXED_LEN / 8; k++) {
-        const uint32_t mask = data[p];
-        const uint32_t nw = data[p + 1];
-        const uint32_t hn = nw >> 4; // n - 1
+        // Two separate byte reads (hipcc would merge plain C byte loads into one 16-bit read, which
+        // at an odd address takes the slow misaligned-LDS path).  The asm waits for its own reads.
+        uint32_t mask, nw;
+        asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(mask), "=&v"(nw)
+                     : "v"(pa)
+                     : "memory");
+        const uint32_t hn = nw >> 4;             // n - 1
+        const uint32_t nz = (mask + 255u) >> 8;  // mask != 0, as arithmetic (no branch, no select)
         const uint32_t cnt = __popc(mask);
-        const int size = mask ? (int)((hn * cnt + cnt + 5) >> 1) : 1; // 2 + (n*cnt + 1) / 2
-        // size > remaining covers every NotEnoughSpace case (an all-zero octet has size 1)
-        bool bad = p + size > end;
-        if constexpr (W == 4) bad |= (hn > 7) & (mask != 0);
-        kbad = (bad && kbad == FIXED_LEN / 8) ? k : kbad;
-        row[k] = (uint32_t)p | (mask << 16) | (nw << 24); // nw is don't-care when mask == 0
+        // octet bytes: 1 if mask == 0, else 2 + (n*cnt + 1)/2  ==  ((hn*cnt + cnt + 3*nz) >> 1) + 1
+        const uint32_t size = ((__umul24(hn, cnt) + (__umul24(nz, 3u) + cnt)) >> 1) + 1u;
+        if constexpr (W == 4) hnmax = max(hnmax, __umul24(hn, nz));
+        row[k] = p | (mask << 16) | (nw << 24);  // nw is don't-care when mask == 0
         p += size;
+        pa += size;
     }
+    // Common case: the cursor ended inside the section and no octet claimed more than 8 nibbles.
     uint32_t err = 0;
-    if (kbad < FIXED_LEN / 8) {
+    if (p > end || hnmax > 7) {
         // exact status of the first failing octet, in the order of the reference's checks
-        // (src/nibblepack_simd.rs:515-557): empty, length < 3, n > 8, payload
-        const uint32_t e = row[kbad];
-        const int pk = (int)(e & 0xffffu), rem = end - pk;
-        const uint32_t mask = (e >> 16) & 0xffu, hn = e >> 28;
-        err = CVEC_NOT_ENOUGH_SPACE;
-        if (W == 4 && rem >= 3 && mask != 0 && hn > 7) err = CVEC_INVALID_FORMAT;
+        // (src/nibblepack_simd.rs:515-557): empty, length < 3, n > 8, payload too long
+        for (int k = 0; k < FIXED_LEN / 8 && !err; k++) {
+            const uint32_t e = row[k];
+            const uint32_t pk = e & 0xffffu, mask = (e >> 16) & 0xffu, hn = e >> 28;
+            const int rem = (int)end - (int)pk;
+            const int size = mask ? (int)(2 + (((hn + 1) * __popc(mask) + 1) >> 1)) : 1;
+            if (rem <= 0) err = CVEC_NOT_ENOUGH_SPACE;
+            else if (mask) {
+                if (W == 4 && rem < 3) err = CVEC_NOT_ENOUGH_SPACE;
+                else if (W == 4 && hn > 7) err = CVEC_INVALID_FORMAT;
+                else if (size > rem || rem < 2) err = CVEC_NOT_ENOUGH_SPACE;
+            }
+        }
     }
     row[ROW_ERR] = err;
 }
