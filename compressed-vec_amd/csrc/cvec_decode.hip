@@ -224,6 +224,7 @@ struct SecShared {
     __attribute__((aligned(16))) uint8_t data[2][LDS_DATA_BYTES + LDS_DATA_PAD];
     __attribute__((aligned(16))) uint32_t octab[2][TILE * OCT_STRIDE];
     ChunkParams P[4];
+    uint32_t ticket[2];
 };
 
 // Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
@@ -233,54 +234,15 @@ __device__ inline uint32_t lds_u16_at(const uint8_t *data, uint32_t p) {
     return __builtin_amdgcn_alignbit(q[1], q[0], (p & 3u) << 3) & 0xffffu;
 }
 
-// One octet element: field `idx` (of width 4n bits) of the little-endian bitstream that follows the
-// two octet header bytes, shifted left by the trailing-zero nibbles; zero lanes give 0.  This is the
-// plain bitstream rule of the format (reference src/nibblepacking.rs:436-470,
-// src/nibblepack_simd.rs:571-585).
-template <int W>
-__device__ inline typename Elem<W>::U extract_elem(const uint8_t *data, uint32_t d, uint32_t j, uint32_t jmask) {
-    const uint32_t addr = d & 0xffffu, mask = (d >> 16) & 0xffu;
-    const uint32_t n4 = ((d >> 28) << 2) + 4, tz = (d >> 22) & 0x3cu;
-    const uint32_t idx = __popc(mask & jmask);
-    const uint32_t bitpos = idx * n4;
-    const uint32_t a = addr + 2 + (bitpos >> 3);
-    const uint32_t s = ((a & 3u) << 3) | (bitpos & 4u);        // bit offset inside the aligned dword
-    const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
-    const bool on = (mask >> j) & 1;
-    if constexpr (W == 4) {
-        uint32_t x = __builtin_amdgcn_alignbit(q[1], q[0], s);
-        x &= 0xffffffffu >> (32 - n4);
-        x = (uint32_t)((uint64_t)x << tz); // a shift count >= 32 yields 0, as the AVX2 lane shift does
-        return on ? x : 0u;
-    } else {
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-        uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, s) |
-                     ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, s) << 32);
-        x &= ~0ull >> (64 - n4);
-        x <<= tz;
-        return on ? x : 0ull;
-    }
-}
-
-// Exclusive XOR scan over the 8 octet groups of a wave (group g = lanes 8g..8g+7, same j = lane & 7):
-// returns XOR of `tot` of the groups before this lane's group.  Pure cross-lane VALU (DPP inside a
-// 16-lane row, v_permlane16_swap between rows, v_permlane32_swap between halves): no LDS round trips.
-__device__ inline uint32_t xor_excl_over_groups(uint32_t tot, int lane) {
-    // odd group of a row <- the even group's value (lanes 0-7 of a row get 0)
-    const uint32_t y = __builtin_amdgcn_update_dpp(0u, tot, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-    const uint32_t t1 = tot ^ y; // odd groups: total of the row's pair
-    // every lane of row r <- the pair total of row r (for its j)
-    const uint32_t pt = __builtin_amdgcn_update_dpp(t1, t1, 0x128 /* row_ror:8 */, 0xf, 0x3, false);
-    const auto s16 = __builtin_amdgcn_permlane16_swap(pt, pt, false, false); // [pt0,pt0,pt2,pt2], [pt1,pt1,pt3,pt3]
-    const uint32_t prev_row = (lane & 16) ? s16[0] : 0u;                      // odd rows: the even row before them
-    const uint32_t q = s16[0] ^ s16[1];                                       // total of the 32-lane half
-    const auto s32 = __builtin_amdgcn_permlane32_swap(q, q, false, false);    // [q.lo, q.lo], [q.hi, q.hi]
-    const uint32_t prev_half = (lane & 32) ? s32[0] : 0u;
-    return y ^ prev_row ^ prev_half;
-}
-
-template <int W> __device__ inline typename Elem<W>::U shfl_up_t(typename Elem<W>::U x, int d) {
-    return __shfl_up(x, d, 64);
+// Inclusive XOR scan over the 32 lanes of each half wave (lane = half*32 + octet), DPP only:
+// shifts by 1, 2, 4, 8 inside a 16-lane row, then lane 15 of rows 0 and 2 into rows 1 and 3.
+__device__ inline uint32_t xor_scan_half(uint32_t x) {
+    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    return x;
 }
 
 template <int ETYPE, bool SINGLE>
@@ -303,105 +265,140 @@ __device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CV
     }
 }
 
-// Decodes section `sec` of a chunk (whole wave): lane (g, j) owns lane j of octets 4g..4g+3, i.e.
-// 4 elements, runs them through the implied XorSink / Delta add and the fused epilogue.
+// Decodes two sections of a chunk with one wave: lane = half*32 + o owns octet o (8 consecutive
+// elements) of section sec0 + half.  The octet's header fields are unpacked once per lane; the 8
+// fields of its bitstream are then pulled with one aligned dword-pair read and one funnel shift
+// each (plain bitstream rule of the format, reference src/nibblepacking.rs:436-470,
+// src/nibblepack_simd.rs:571-585), run through the implied XorSink / Delta add and the fused
+// epilogue.  Section kinds are handled by selects, so the two halves may hold different kinds.
 template <int ETYPE, int MODE, bool SINGLE>
-__device__ inline void decode_section(const uint8_t *data, const uint32_t *row, uint64_t slot, int lane,
-                                      const PredArgs &pa, const SinkArgs &sa, uint32_t *__restrict__ sec_res,
-                                      uint8_t *__restrict__ masks, void *__restrict__ out_) {
+__device__ inline void decode_pair(const uint8_t *data, const uint32_t *octab, uint32_t sec0, uint32_t nsec,
+                                   uint64_t slot0, int lane, const PredArgs &pa, const SinkArgs &sa,
+                                   uint32_t *__restrict__ sec_res, uint8_t *__restrict__ masks,
+                                   void *__restrict__ out_) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
-    const uint32_t g = lane >> 3, j = lane & 7, jmask = (1u << j) - 1u;
+    const uint32_t half = (uint32_t)lane >> 5, o = lane & 31;
+    const bool live = sec0 + half < nsec;
+    const uint32_t sec = live ? sec0 + half : sec0;
+    const uint32_t *row = octab + sec * OCT_STRIDE;
     const uint4 meta = *(const uint4 *)(row + ROW_ERR);
-    const uint4 tab = *(const uint4 *)(row + 4 * g); // issued with the meta read: one LDS round trip
-    const uint32_t err = __builtin_amdgcn_readfirstlane(meta.x);
-    const uint32_t kind = __builtin_amdgcn_readfirstlane(meta.y);
-    const uint32_t rel = __builtin_amdgcn_readfirstlane(meta.z);
-    uint32_t res;
-    if (kind == K_SKIP) {
-        res = res_pack(0, 0);
-    } else if (kind == K_ILLEGAL) {
-        res = res_pack(0, CVEC_INVALID_FORMAT);
-    } else if (err) {
-        res = res_pack(0, err);
-    } else {
-        U x[4];
-        bool zeroes = false; // the section reaches the sink through process_zeroes()
-        if (kind == K_NULL) {
-            x[0] = x[1] = x[2] = x[3] = 0;
-            zeroes = true;
-        } else if (kind == K_CONST) {
-            // value at section byte 1: aligned dwords + funnel shift
-            const uint32_t a = rel + 1;
-            const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
-            const uint32_t s = (a & 3u) << 3;
-            U v;
-            if constexpr (W == 4) v = __builtin_amdgcn_alignbit(q[1], q[0], s);
-            else v = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
-                     ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
-            x[0] = x[1] = x[2] = x[3] = v;
-        } else {
-            x[0] = extract_elem<W>(data, tab.x, j, jmask);
-            x[1] = extract_elem<W>(data, tab.y, j, jmask);
-            x[2] = extract_elem<W>(data, tab.z, j, jmask);
-            x[3] = extract_elem<W>(data, tab.w, j, jmask);
-            if (ETYPE == CVEC_F32) {
-                // XorSink: out[k] = out[k-1] ^ x[k] per lane j, state zero at the section start
-                // (src/sink.rs:271-275, src/section.rs:707): serial over the lane's 4 octets, then an
-                // exclusive scan over the 8 octet groups (lane strides 8, 16, 32), all in registers.
-                x[1] ^= x[0]; x[2] ^= x[1]; x[3] ^= x[2];
-                const uint32_t excl = xor_excl_over_groups((uint32_t)x[3], lane);
-                x[0] ^= excl; x[1] ^= excl; x[2] ^= excl; x[3] ^= excl;
-            } else if (kind == K_DELTA) {
-                // AddConstSink(base) around the octet decode (src/section.rs:636-641), wrapping
-                const uint32_t a = rel + 4;
-                const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
-                const uint32_t s = (a & 3u) << 3;
-                U base;
-                if constexpr (W == 4) base = __builtin_amdgcn_alignbit(q[1], q[0], s);
-                else base = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
-                            ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
-                x[0] += base; x[1] += base; x[2] += base; x[3] += base;
-            }
+    uint32_t d = row[o];
+    const uint32_t err = meta.x, kind = meta.y, rel = meta.z;
+    const bool isoct = (kind == K_NP || kind == K_DELTA || kind == K_XOR) && err == 0;
+    const bool isconst = kind == K_CONST, isdelta = kind == K_DELTA;
+    d = isoct ? d : 0u; // mask 0: every element of the lane is zero, reads stay at the buffer start
+
+    // Const value (section byte 1) or Delta base (section byte 4): aligned dwords + funnel shift
+    U v;
+    {
+        const uint32_t a = (isconst || isdelta) ? rel + (isconst ? 1u : 4u) : 0u;
+        const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
+        const uint32_t s = (a & 3u) << 3;
+        if constexpr (W == 4) v = __builtin_amdgcn_alignbit(q[1], q[0], s);
+        else v = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
+                 ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
+    }
+
+    // ---- the lane's octet ---------------------------------------------------------------------------
+    const uint32_t mask = (d >> 16) & 0xffu, hn = d >> 28;
+    const uint32_t n4 = (hn << 2) + 4u;          // field width in bits
+    const uint32_t t4 = (d >> 22) & 0x3cu;       // trailing zero bits
+    uint32_t pb = ((d & 0xffffu) << 3) + 16u;    // bit position of the next stored field
+    U x[8];
+    if constexpr (W == 4) {
+        // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
+        const uint32_t fm = t4 >= 32u ? 0u : 0xffffffffu >> (32u - n4);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t sm = (uint32_t)((int32_t)(mask << (31 - k)) >> 31); // all ones iff element k is stored
+            const uint32_t *q = (const uint32_t *)(data + ((pb >> 3) & ~3u));
+            const uint32_t f = __builtin_amdgcn_alignbit(q[1], q[0], pb);       // uses pb & 31
+            x[k] = ((f & fm) << (t4 & 31u)) & sm;
+            pb += n4 & sm;
         }
-        if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
-            uint32_t cnt = 0;
-            if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
-                cnt = pa.match_zero ? FIXED_LEN : 0;
-                if (MODE == MODE_FILTER_MASKS && lane < 8)
-                    ((uint32_t *)(masks + slot * 32))[lane] = pa.match_zero ? ~0u : 0u;
-            } else {
-                uint32_t mword = 0;
+    } else {
+        const uint64_t fm = ~0ull >> (64u - n4);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    unsigned long long b = __ballot(pred_match<ETYPE, SINGLE>(pa, x[i]));
-                    cnt += __popcll(b);
-                    if (MODE == MODE_FILTER_MASKS) mword |= (uint32_t)((b >> (8 * g)) & 0xffu) << (8 * i);
-                }
-                if (MODE == MODE_FILTER_MASKS && j == 0) ((uint32_t *)(masks + slot * 32))[g] = mword;
-            }
-            res = res_pack(cnt, 0);
-        } else {
-            if (sa.add_const) {
-                // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards the
-                // base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
-                if constexpr (ETYPE == CVEC_F32) {
-                    const float b = __uint_as_float((uint32_t)sa.base);
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        x[i] = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x[i]) + b);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) x[i] += (U)sa.base;
-                }
-            }
-            U *o = (U *)out_ + slot * FIXED_LEN + 32 * g + j;
-#pragma unroll
-            for (int i = 0; i < 4; i++) o[8 * i] = x[i];
-            res = res_pack(FIXED_LEN, 0);
+        for (int k = 0; k < 8; k++) {
+            const uint32_t sm = (uint32_t)((int32_t)(mask << (31 - k)) >> 31);
+            const uint32_t *q = (const uint32_t *)(data + ((pb >> 3) & ~3u));
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            const uint64_t f = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, pb) |
+                               ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, pb) << 32);
+            x[k] = ((f & fm) << t4) & (uint64_t)(int64_t)(int32_t)sm;
+            pb += n4 & sm;
         }
     }
-    if (lane == 0) sec_res[slot] = res;
+    if constexpr (ETYPE == CVEC_F32) {
+        // XorSink: out[i] = out[i-8] ^ x[i], state zero at the section start (src/sink.rs:271-275,
+        // src/section.rs:707): per element index k an inclusive scan over the section's 32 octets.
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = xor_scan_half((uint32_t)x[k]);
+    } else {
+        // AddConstSink(base) around the octet decode of a Delta section (src/section.rs:636-641), wrapping
+        const U base = isdelta ? v : (U)0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] += base;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = isconst ? v : x[k];
+
+    // ---- per-section status ----------------------------------------------------------------------------
+    uint32_t status = err;
+    if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
+    const bool skip = kind == K_SKIP;
+    const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
+    const bool ok = live && !skip && status == 0;
+    uint32_t count;
+    if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
+        uint32_t c_lo = 0, c_hi = 0, mbyte = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool m = pred_match<ETYPE, SINGLE>(pa, x[k]);
+            const unsigned long long b = __ballot(m);
+            c_lo += __popc((uint32_t)b);
+            c_hi += __popc((uint32_t)(b >> 32));
+            if constexpr (MODE == MODE_FILTER_MASKS) mbyte |= m ? (1u << k) : 0u;
+        }
+        count = half ? c_hi : c_lo;
+        if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
+            count = pa.match_zero ? FIXED_LEN : 0;
+            mbyte = pa.match_zero ? 0xffu : 0u;
+        }
+        if constexpr (MODE == MODE_FILTER_MASKS) {
+            if (ok) masks[(slot0 + half) * 32 + o] = (uint8_t)mbyte;
+        }
+    } else {
+        if (sa.add_const) {
+            // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards the
+            // base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
+            if constexpr (ETYPE == CVEC_F32) {
+                const float bf = __uint_as_float((uint32_t)sa.base);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    x[k] = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x[k]) + bf);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] += (U)sa.base;
+            }
+        }
+        if (ok) {
+            // 8 consecutive elements per lane, lanes consecutive: full-line stores
+            U *op = (U *)out_ + (slot0 + half) * FIXED_LEN + 8 * o;
+            if constexpr (W == 4) {
+                ((uint4 *)op)[0] = make_uint4(x[0], x[1], x[2], x[3]);
+                ((uint4 *)op)[1] = make_uint4(x[4], x[5], x[6], x[7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    ((uint4 *)op)[k] = make_uint4((uint32_t)x[2 * k], (uint32_t)(x[2 * k] >> 32),
+                                                  (uint32_t)x[2 * k + 1], (uint32_t)(x[2 * k + 1] >> 32));
+            }
+        }
+        count = FIXED_LEN;
+    }
+    if (live && o == 0) sec_res[slot0 + half] = skip ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
 }
 
 // The octet walk of one section by one lane: 32 dependent steps, each one LDS round trip (two byte
@@ -504,16 +501,18 @@ __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__re
     uint32_t r_nchunks = 0;
 
     for (uint32_t t = 0;; t++) {
+        uint64_t gb = 0, s_next = 0, d_next = 0;
+        int n = 0;
         if (wave == 0) {
             // ---- extent of chunk t: longest run of sections from s_cur whose span fits a buffer -----
             const uint64_t left = s_cur < sB ? sB - s_cur : 0;
             const int avail = (int)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
             const uint64_t off = desc_off(d_cur);
-            const uint64_t gb = __shfl(off, 0, 64) & ~15ull;
+            gb = __shfl(off, 0, 64) & ~15ull;
             const uint64_t endl = off + clip_len(d_cur) - gb; // wraps to a huge value if off < gb
             const bool fits = lane >= avail || endl <= (uint64_t)LDS_DATA_BYTES;
             const unsigned long long m = __ballot(fits);
-            int n = m == ~0ull ? avail : __builtin_ctzll(~m);
+            n = m == ~0ull ? avail : __builtin_ctzll(~m);
             n = n < avail ? n : avail;
             uint32_t e = lane < n ? (uint32_t)endl : 0u;
 #pragma unroll
@@ -524,8 +523,8 @@ __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__re
                 sm.P[t & 3] = cp;
             }
             // descriptors of chunk t+1 start where chunk t ends
-            const uint64_t s_next = s_cur + (uint64_t)n;
-            const uint64_t d_next = load_desc(s_next);
+            s_next = s_cur + (uint64_t)n;
+            d_next = load_desc(s_next);
             // ---- walk chunk t-2 -----------------------------------------------------------------------
             if (t >= 2 && sa._pad != 1) {
                 const uint32_t nw = sm.P[(t - 2) & 3].n;
@@ -535,8 +534,28 @@ __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__re
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
-            // ---- barrier X ----
-            __syncthreads();
+        }
+        // ---- decode chunk t-3: every wave draws section pairs from the chunk's ticket counter (the walker
+        //      joins once its chain is done), the next ticket being fetched while the current pair decodes ---
+        if (t >= 3 && sa._pad == 0) {
+            const ChunkParams cp = sm.P[(t - 3) & 3];
+            const uint32_t nd = __builtin_amdgcn_readfirstlane(cp.n);
+            const uint32_t npairs = (nd + 1) >> 1;
+            uint32_t *tk = &sm.ticket[(t - 3) & 1];
+            uint32_t nxt = 0;
+            if (lane == 0) nxt = atomicAdd(tk, 1u);
+            nxt = __builtin_amdgcn_readfirstlane(nxt);
+            while (nxt < npairs) {
+                const uint32_t cur = nxt;
+                if (lane == 0) nxt = atomicAdd(tk, 1u);
+                decode_pair<ETYPE, MODE, SINGLE>(sm.data[(t - 3) & 1], sm.octab[(t - 3) & 1], 2 * cur, nd,
+                                                 cp.s0 + 2 * cur, lane, pa, sa, sec_res, masks, out_);
+                nxt = __builtin_amdgcn_readfirstlane(nxt);
+            }
+        }
+        // ---- barrier X ----
+        __syncthreads();
+        if (wave == 0) {
             if (t >= 1 && (uint32_t)lane < n_prev) {
                 uint32_t *row = sm.octab[(t - 1) & 1] + lane * OCT_STRIDE;
                 row[ROW_LEN] = clip_len(d_prev);
@@ -544,21 +563,10 @@ __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__re
                 row[ROW_REL] = (uint32_t)(desc_off(d_prev) - gbase_prev);
                 row[ROW_ERR] = 0;
             }
+            if (lane == 0) sm.ticket[(t - 1) & 1] = 0;
             // shift the descriptor window: next step writes the table rows of chunk t from d_prev
             d_prev = d_cur; d_cur = d_next;
             gbase_prev = gb; n_prev = (uint32_t)n; s_cur = s_next;
-        } else {
-            // ---- decode chunk t-3 ------------------------------------------------------------------------
-            if (t >= 3 && sa._pad == 0) {
-                const ChunkParams cp = sm.P[(t - 3) & 3];
-                const uint32_t nd = __builtin_amdgcn_readfirstlane(cp.n);
-                for (uint32_t sec = (uint32_t)wave - 1; sec < nd; sec += N_DECODE_WAVES)
-                    decode_section<ETYPE, MODE, SINGLE>(sm.data[(t - 3) & 1],
-                                                        sm.octab[(t - 3) & 1] + sec * OCT_STRIDE, cp.s0 + sec, lane,
-                                                        pa, sa, sec_res, masks, out_);
-            }
-            // ---- barrier X ----
-            __syncthreads();
         }
         // ---- write chunk t-1 (registers -> the buffer chunk t-3 vacated), issue the loads of chunk t -----
         if (t >= 1) {
