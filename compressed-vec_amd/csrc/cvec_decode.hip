@@ -193,24 +193,26 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
 // ------------------------------------------------------------------------------------------------
 // k_sections
 // ------------------------------------------------------------------------------------------------
-constexpr int TILE = 32;            // section slots per workgroup
-// Octet table: one 36-dword row per section (rows are 16-byte aligned so a lane fetches the four
-// octets it owns with one ds_read_b128).  Entries 0..31: LDS byte address of the octet (16 bits) |
-// nonzero mask (8) | nibble word (8).  Entries 32..35: per-section err, kind, LDS start, byte length.
+constexpr int TILE = 16;            // section slots per chunk (= walker lanes in use)
+// Octet table: one 36-dword row per section (rows are 16-byte aligned and 36 is bank-conflict free
+// for the walker's per-lane rows).  Entries 0..31: byte address of the octet inside the staging slot
+// (16 bits) | nonzero mask (8) | nibble word (8).  Entries 32..35: per-section err, kind, start, length.
 constexpr int OCT_STRIDE = 36;
 constexpr int ROW_ERR = 32, ROW_KIND = 33, ROW_REL = 34, ROW_LEN = 35;
-// LDS: the staged span covers 32 worst-case u32/f32 sections (1100 B) + the vector headers between
-// them + alignment; with the table a workgroup stays under 40 KiB, so four share a CU's 160 KiB.
-constexpr uint32_t LDS_DATA_BYTES = 35744;
-constexpr uint32_t LDS_DATA_PAD = 16;
+// Staging slot: 18 KiB = 18 LDS-DMA wave instructions of 1 KiB; holds 16 worst-case u32/f32
+// sections (1100 B) plus the vector headers between them.  Four slots + two tables stay under
+// 80 KiB, so two workgroups share a CU's 160 KiB.
+constexpr int SLOT_PIECES = 18;
+constexpr uint32_t SLOT_BYTES = SLOT_PIECES * 1024;
+constexpr int N_SLOTS = 4;
+static_assert(SLOT_PIECES == 18, "the loader's s_waitcnt vmcnt(18) counts SLOT_PIECES instructions");
 
 enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2 };
 
-constexpr int SEC_THREADS = 512;                      // wave 0 walks, waves 1..7 decode
-constexpr int N_DECODE_WAVES = SEC_THREADS / 64 - 1;
-constexpr int STAGE_IT = (LDS_DATA_BYTES / 16 + SEC_THREADS - 1) / SEC_THREADS;
+constexpr int SEC_THREADS = 512; // wave 0 walks, wave 1 plans, wave 7 loads, every wave but 7 decodes
+constexpr int LOADER_WAVE = SEC_THREADS / 64 - 1;
 
-// A chunk = up to TILE consecutive section slots whose bytes fit one staging buffer as one span.
+// A chunk = up to TILE consecutive section slots whose bytes fit one staging slot as one span.
 struct ChunkParams {
     uint64_t s0;      // first section slot
     uint64_t gbase;   // 16-byte aligned blob offset of the span
@@ -218,14 +220,25 @@ struct ChunkParams {
     uint32_t nchunks; // 16-byte pieces of the span
 };
 
-// Two staging buffers + two octet tables: while chunk c is decoded out of one pair, chunk c+1 is
-// walked in the other.  80.8 KB per workgroup, so two workgroups share a CU's 160 KiB.
 struct SecShared {
-    __attribute__((aligned(16))) uint8_t data[2][LDS_DATA_BYTES + LDS_DATA_PAD];
+    __attribute__((aligned(16))) uint8_t data[N_SLOTS][SLOT_BYTES];
     __attribute__((aligned(16))) uint32_t octab[2][TILE * OCT_STRIDE];
-    ChunkParams P[4];
+    __attribute__((aligned(16))) uint4 meta[8][TILE]; // {0, kind, start inside the slot, length} per section
+    ChunkParams P[8];
     uint32_t ticket[2];
 };
+
+// One LDS-DMA wave instruction: lane l copies 16 bytes from its own global address to LDS byte
+// address lds_dst + 16*l (lds_dst wave-uniform).  Nothing lands in registers and the compiler does
+// not count it: completion is waited for with an explicit s_waitcnt vmcnt.  M0 (the LDS base of the
+// instruction) is saved and restored inside the statement.
+__device__ inline void lds_dma16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
 
 // Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
 // LDS read here is a naturally aligned dword pair / triple that is then funnel-shifted.
@@ -347,6 +360,12 @@ __device__ inline void decode_pair(const uint8_t *data, const uint32_t *octab, u
     // ---- per-section status ----------------------------------------------------------------------------
     uint32_t status = err;
     if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
+    if constexpr (W == 4) {
+        // a stored octet of a 32-bit section claiming more than 8 nibbles (src/nibblepack_simd.rs:541):
+        // every octet before it fitted, so it is the section's first error
+        const unsigned long long wide = __ballot(mask != 0 && hn > 7);
+        if (((uint32_t)(half ? wide >> 32 : wide)) != 0 && status == 0) status = CVEC_INVALID_FORMAT;
+    }
     const bool skip = kind == K_SKIP;
     const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
     const bool ok = live && !skip && status == 0;
@@ -401,15 +420,18 @@ __device__ inline void decode_pair(const uint8_t *data, const uint32_t *octab, u
     if (live && o == 0) sec_res[slot0 + half] = skip ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
 }
 
-// The octet walk of one section by one lane: 32 dependent steps, each one LDS round trip (two byte
-// reads, always aligned) plus a short chain popc -> mad -> shift -> select -> add, branch-free and
-// with as few instructions beside the chain as possible (a lone wave issues one VALU op per ~4
-// cycles, so every extra instruction per step is paid 32 times on the critical path).  The loop
-// only remembers the first suspicious octet; its exact status is worked out afterwards.  After an
-// error the cursor keeps moving over garbage (reads stay inside the workgroup's LDS allocation or
-// return 0); the sticky error decides the section's result.
+// The octet walk of one section by one lane: 32 dependent steps.  A step's critical chain is one
+// LDS round trip (two byte reads, always aligned) and eight VALU operations ending in the next
+// cursor; the reads of the next octet are issued as soon as that cursor is known, and the table
+// entry of the current octet is packed and stored in the shadow of their latency.  Branch-free; a
+// lone wave issues one VALU operation per ~4 cycles, so every instruction in the chain is paid 32
+// times.  The loop only notices a cursor that ends past the section; the exact status of the first
+// failing octet is worked out afterwards.  After an error the cursor keeps moving over garbage
+// (reads stay inside the workgroup's LDS allocation or return 0); the error decides the section's
+// result.  An octet of a 32-bit section claiming more than 8 nibbles is left to the decoder, which
+// sees every octet header anyway (the walk itself does not depend on it).
 template <int W>
-__device__ inline void walk_section(const uint8_t *data, uint32_t *row) {
+__device__ __forceinline__ void walk_section(const uint8_t *data, uint32_t *row) {
     const uint32_t kind = row[ROW_KIND];
     if (!(kind == K_NP || kind == K_DELTA || kind == K_XOR)) return;
     const uint32_t rel = row[ROW_REL];
@@ -417,38 +439,46 @@ __device__ inline void walk_section(const uint8_t *data, uint32_t *row) {
     uint32_t p = rel + (kind == K_DELTA ? DELTA_HDR : 3);
     // same cursor as a raw LDS byte address, advanced beside p (not behind it)
     uint32_t pa = (uint32_t)(uintptr_t)data + p;
-    uint32_t hnmax = 0;
+    // Two separate byte reads (hipcc would merge plain C byte loads into one 16-bit read, which at
+    // an odd address takes the slow misaligned-LDS path).
+    uint32_t mask, nw;
+    asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(mask), "=&v"(nw)
+                 : "v"(pa)
+                 : "memory");
 #pragma unroll 8
     for (int k = 0; k < FIXED_LEN / 8; k++) {
-        // Two separate byte reads (hipcc would merge plain C byte loads into one 16-bit read, which
-        // at an odd address takes the slow misaligned-LDS path).  The asm waits for its own reads.
-        uint32_t mask, nw;
-        asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(mask), "=&v"(nw)
+        // octet bytes: 1 if mask == 0, else 2 + (n*cnt + 1)/2  ==  (hn*cnt + cnt + 2 + 3*[mask != 0]) >> 1
+        const uint32_t hn = nw >> 4; // n - 1
+        const uint32_t cnt = __popc(mask);
+        const uint32_t a = (uint32_t)__umul24(min(mask, 1u), 3u) + (cnt + 2u);
+        const uint32_t size = ((uint32_t)__umul24(hn, cnt) + a) >> 1;
+        pa += size;
+        // Reads of the next octet (after the last one: a harmless read of the byte that follows).
+        // mask and nw pass through the statement so that the packing below is scheduled behind it.
+        uint32_t mask_n, nw_n;
+        asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1"
+                     : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
                      : "v"(pa)
                      : "memory");
-        const uint32_t hn = nw >> 4;             // n - 1
-        const uint32_t nz = (mask + 255u) >> 8;  // mask != 0, as arithmetic (no branch, no select)
-        const uint32_t cnt = __popc(mask);
-        // octet bytes: 1 if mask == 0, else 2 + (n*cnt + 1)/2  ==  ((hn*cnt + cnt + 3*nz) >> 1) + 1
-        const uint32_t size = ((__umul24(hn, cnt) + (__umul24(nz, 3u) + cnt)) >> 1) + 1u;
-        if constexpr (W == 4) hnmax = max(hnmax, __umul24(hn, nz));
-        row[k] = p | (mask << 16) | (nw << 24);  // nw is don't-care when mask == 0
+        row[k] = p | (mask << 16) | (nw << 24); // nw is don't-care when mask == 0
         p += size;
-        pa += size;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mask_n), "+v"(nw_n) : : "memory");
+        mask = mask_n;
+        nw = nw_n;
     }
-    // Common case: the cursor ended inside the section and no octet claimed more than 8 nibbles.
+    // Common case: the cursor ended inside the section.
     uint32_t err = 0;
-    if (p > end || hnmax > 7) {
+    if (p > end) {
         // exact status of the first failing octet, in the order of the reference's checks
         // (src/nibblepack_simd.rs:515-557): empty, length < 3, n > 8, payload too long
         for (int k = 0; k < FIXED_LEN / 8 && !err; k++) {
             const uint32_t e = row[k];
-            const uint32_t pk = e & 0xffffu, mask = (e >> 16) & 0xffu, hn = e >> 28;
+            const uint32_t pk = e & 0xffffu, mk = (e >> 16) & 0xffu, hn = e >> 28;
             const int rem = (int)end - (int)pk;
-            const int size = mask ? (int)(2 + (((hn + 1) * __popc(mask) + 1) >> 1)) : 1;
+            const int size = mk ? (int)(2 + (((hn + 1) * __popc(mk) + 1) >> 1)) : 1;
             if (rem <= 0) err = CVEC_NOT_ENOUGH_SPACE;
-            else if (mask) {
+            else if (mk) {
                 if (W == 4 && rem < 3) err = CVEC_NOT_ENOUGH_SPACE;
                 else if (W == 4 && hn > 7) err = CVEC_INVALID_FORMAT;
                 else if (size > rem || rem < 2) err = CVEC_NOT_ENOUGH_SPACE;
@@ -459,15 +489,16 @@ __device__ inline void walk_section(const uint8_t *data, uint32_t *row) {
 }
 
 // k_sections: persistent workgroups, each owning a contiguous range of section slots, run a
-// four-stage software pipeline over chunks of that range.  In step t:
-//     wave 0            computes the extent of chunk t from its descriptors, then walks chunk t-2
-//     waves 1..7        decode chunk t-3                                   (other LDS buffer pair)
-//   -- barrier --
-//     all waves         write chunk t-1 (held in registers) into the buffer chunk t-3 just vacated,
-//                       then issue the global loads of chunk t into registers
-//   -- barrier --
-// so the HBM latency of a chunk is hidden behind a whole step, the serial octet walk of one chunk
-// runs beside the decode of another, and the blob is streamed at a steady rate.
+// five-stage software pipeline over chunks of that range with ONE barrier per step.  In step t:
+//     wave 1     plans chunk t (extent from the descriptors)
+//     wave 0     walks the octets of chunk t-3
+//     wave 7     issues the LDS-DMA loads of chunk t-1 into the slot chunk t-5 vacated and waits until
+//                chunk t-2 has landed; it does nothing else, so a full memory queue stalls only it
+//     all but 7  decode chunk t-4, drawing section pairs from a ticket counter (waves 0 and 1
+//                join when their own job is done)
+// A chunk's bytes therefore have two whole steps to arrive, the blob streams at a steady rate
+// whatever the compute waves do, and the serial octet walk of one chunk runs beside the decode of
+// another.
 template <int ETYPE, int MODE, bool SINGLE>
 __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
@@ -477,12 +508,13 @@ __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__re
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared sm;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t sA = (uint64_t)blockIdx.x * sections_per_wg;
     const uint64_t sB = sA + sections_per_wg < n_sections ? sA + sections_per_wg : n_sections;
     if (sA >= sB) return;
 
-    // control state, meaningful in wave 0 only (lanes 0..TILE-1 hold one descriptor each)
+    // planning state, meaningful in wave 1 only (lanes 0..TILE-1 hold one descriptor each)
     auto load_desc = [&](uint64_t s) -> uint64_t {
         return (lane < TILE && s + (uint64_t)lane < sB) ? desc[s + lane] : desc_pack(0, 0, K_SKIP);
     };
@@ -490,109 +522,92 @@ __global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__re
         const uint32_t len = desc_len(d);
         return len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
     };
-    uint64_t d_prev = desc_pack(0, 0, K_SKIP), d_cur = desc_pack(0, 0, K_SKIP);
-    uint64_t s_cur = sA, gbase_prev = 0;
-    uint32_t n_prev = 0;
-    if (wave == 0) d_cur = load_desc(sA);
-
-    uint4 R[STAGE_IT];
-#pragma unroll
-    for (int it = 0; it < STAGE_IT; it++) R[it] = make_uint4(0, 0, 0, 0);
-    uint32_t r_nchunks = 0;
+    uint64_t d_cur = desc_pack(0, 0, K_SKIP), s_cur = sA;
+    // Two workgroups share a CU and wave w of a workgroup runs on SIMD w % 4: the latency-critical
+    // walkers of co-resident workgroups (block ids 256 apart in dispatch order) go to different SIMDs.
+    const int walker_wave = ((blockIdx.x >> 8) & 1) * 2, planner_wave = walker_wave + 1;
+    if (wave == planner_wave) d_cur = load_desc(sA);
 
     for (uint32_t t = 0;; t++) {
-        uint64_t gb = 0, s_next = 0, d_next = 0;
-        int n = 0;
-        if (wave == 0) {
-            // ---- extent of chunk t: longest run of sections from s_cur whose span fits a buffer -----
+        if (wave == planner_wave) {
+            // ---- plan chunk t: longest run of sections from s_cur whose span fits a slot ---------------
             const uint64_t left = s_cur < sB ? sB - s_cur : 0;
             const int avail = (int)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
             const uint64_t off = desc_off(d_cur);
-            gb = __shfl(off, 0, 64) & ~15ull;
-            const uint64_t endl = off + clip_len(d_cur) - gb; // wraps to a huge value if off < gb
-            const bool fits = lane >= avail || endl <= (uint64_t)LDS_DATA_BYTES;
+            const uint64_t gb = __shfl(off, 0, 64) & ~15ull;
+            const uint32_t len = clip_len(d_cur);
+            const uint64_t endl = off + len - gb; // wraps to a huge value if off < gb
+            const bool fits = lane >= avail || endl <= (uint64_t)SLOT_BYTES;
             const unsigned long long m = __ballot(fits);
-            n = m == ~0ull ? avail : __builtin_ctzll(~m);
+            int n = m == ~0ull ? avail : __builtin_ctzll(~m);
             n = n < avail ? n : avail;
             uint32_t e = lane < n ? (uint32_t)endl : 0u;
 #pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(e, d, 64); e = o > e ? o : e; }
+            for (int d = 8; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(e, d, 64); e = o > e ? o : e; }
             if (lane == 0) {
                 ChunkParams cp;
                 cp.s0 = s_cur; cp.gbase = gb; cp.n = (uint32_t)n; cp.nchunks = (e + 15) >> 4;
-                sm.P[t & 3] = cp;
+                sm.P[t & 7] = cp;
+                sm.ticket[(t + 1) & 1] = 0; // counter of chunk t-3, decoded in the next step
             }
+            if (lane < n) sm.meta[t & 7][lane] = make_uint4(0u, desc_kind(d_cur), (uint32_t)(off - gb), len);
             // descriptors of chunk t+1 start where chunk t ends
-            s_next = s_cur + (uint64_t)n;
-            d_next = load_desc(s_next);
-            // ---- walk chunk t-2 -----------------------------------------------------------------------
-            if (t >= 2 && sa._pad != 1) {
-                const uint32_t nw = sm.P[(t - 2) & 3].n;
+            s_cur += (uint64_t)n;
+            d_cur = load_desc(s_cur);
+        } else if (wave == walker_wave) {
+            // ---- walk chunk t-3 -----------------------------------------------------------------------
+            if (t >= 3 && sa._pad != 1) {
+                const uint32_t nw = sm.P[(t - 3) & 7].n;
                 if ((uint32_t)lane < nw) {
-                    __builtin_amdgcn_s_setprio(3); // seven waves will wait on this chain at the barrier
-                    walk_section<W>(sm.data[t & 1], sm.octab[t & 1] + lane * OCT_STRIDE);
+                    uint32_t *row = sm.octab[(t - 3) & 1] + lane * OCT_STRIDE;
+                    *(uint4 *)(row + ROW_ERR) = sm.meta[(t - 3) & 7][lane];
+                    __builtin_amdgcn_s_setprio(3); // the other waves will wait on this chain at the barrier
+                    walk_section<W>(sm.data[(t - 3) & 3], row);
                     __builtin_amdgcn_s_setprio(0);
                 }
             }
+        } else if (wave == LOADER_WAVE) {
+            // ---- LDS-DMA loads of chunk t-1; afterwards everything but those has landed ------------------
+            uint32_t nch = 0;
+            ChunkParams cp;
+            if (t >= 1) {
+                cp = sm.P[(t - 1) & 7];
+                nch = __builtin_amdgcn_readfirstlane(cp.n) ? __builtin_amdgcn_readfirstlane(cp.nchunks) : 0u;
+            }
+            if (nch && sa._pad != 3) {
+                const uint8_t *src = bytes + cp.gbase;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sm.data[(t - 1) & 3][0]);
+#pragma unroll
+                for (int i = 0; i < SLOT_PIECES; i++) {
+                    const uint32_t c = (uint32_t)lane + 64u * i;
+                    // always SLOT_PIECES instructions (the wait below counts them); lanes past the
+                    // span re-read piece 0
+                    lds_dma16(src + 16ull * (c < nch ? c : 0u), dst + 1024u * i);
+                }
+                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
-        // ---- decode chunk t-3: every wave draws section pairs from the chunk's ticket counter (the walker
-        //      joins once its chain is done), the next ticket being fetched while the current pair decodes ---
-        if (t >= 3 && sa._pad == 0) {
-            const ChunkParams cp = sm.P[(t - 3) & 3];
+        // ---- decode chunk t-4: section pairs by ticket, the next ticket fetched while a pair decodes ------
+        if (wave != LOADER_WAVE && t >= 4 && sa._pad == 0) {
+            const ChunkParams cp = sm.P[(t - 4) & 7];
             const uint32_t nd = __builtin_amdgcn_readfirstlane(cp.n);
             const uint32_t npairs = (nd + 1) >> 1;
-            uint32_t *tk = &sm.ticket[(t - 3) & 1];
+            uint32_t *tk = &sm.ticket[(t - 4) & 1];
             uint32_t nxt = 0;
             if (lane == 0) nxt = atomicAdd(tk, 1u);
             nxt = __builtin_amdgcn_readfirstlane(nxt);
             while (nxt < npairs) {
                 const uint32_t cur = nxt;
                 if (lane == 0) nxt = atomicAdd(tk, 1u);
-                decode_pair<ETYPE, MODE, SINGLE>(sm.data[(t - 3) & 1], sm.octab[(t - 3) & 1], 2 * cur, nd,
+                decode_pair<ETYPE, MODE, SINGLE>(sm.data[(t - 4) & 3], sm.octab[(t - 4) & 1], 2 * cur, nd,
                                                  cp.s0 + 2 * cur, lane, pa, sa, sec_res, masks, out_);
                 nxt = __builtin_amdgcn_readfirstlane(nxt);
             }
         }
-        // ---- barrier X ----
         __syncthreads();
-        if (wave == 0) {
-            if (t >= 1 && (uint32_t)lane < n_prev) {
-                uint32_t *row = sm.octab[(t - 1) & 1] + lane * OCT_STRIDE;
-                row[ROW_LEN] = clip_len(d_prev);
-                row[ROW_KIND] = desc_kind(d_prev);
-                row[ROW_REL] = (uint32_t)(desc_off(d_prev) - gbase_prev);
-                row[ROW_ERR] = 0;
-            }
-            if (lane == 0) sm.ticket[(t - 1) & 1] = 0;
-            // shift the descriptor window: next step writes the table rows of chunk t from d_prev
-            d_prev = d_cur; d_cur = d_next;
-            gbase_prev = gb; n_prev = (uint32_t)n; s_cur = s_next;
-        }
-        // ---- write chunk t-1 (registers -> the buffer chunk t-3 vacated), issue the loads of chunk t -----
-        if (t >= 1) {
-            uint4 *dst = (uint4 *)sm.data[(t - 1) & 1];
-#pragma unroll
-            for (int it = 0; it < STAGE_IT; it++) {
-                const uint32_t c = tid + it * SEC_THREADS;
-                if (c < r_nchunks) dst[c] = R[it];
-            }
-        }
-        {
-            const ChunkParams cp = sm.P[t & 3];
-            const uint32_t nch = __builtin_amdgcn_readfirstlane(cp.n) ? __builtin_amdgcn_readfirstlane(cp.nchunks) : 0u;
-            r_nchunks = nch;
-            if (nch) {
-                const uint4 *src = (const uint4 *)(bytes + cp.gbase);
-#pragma unroll
-                for (int it = 0; it < STAGE_IT; it++) {
-                    const uint32_t c = tid + it * SEC_THREADS;
-                    R[it] = src[c < nch ? c : 0u]; // lanes past the span re-read piece 0 (cheap, keeps R in registers)
-                }
-            }
-        }
-        // ---- barrier Y ----
-        __syncthreads();
-        if (t >= 2 && sm.P[(t - 2) & 3].n == 0) break; // chunk t-2 does not exist: nothing left in flight
+        if (t >= 4 && sm.P[(t - 4) & 7].n == 0) break; // chunk t-4 does not exist: nothing is in flight any more
     }
 }
 
@@ -733,9 +748,10 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
     if (ns > 0) {
         // Persistent workgroups: two fit a CU (LDS), so 2 x 256 x 2 rounds; each owns a contiguous
         // range of section slots (a multiple of TILE) and pipelines over it.
-        uint64_t per = (ns + 1023) / 1024;
+        static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 2; }();
+        uint64_t per = (ns + 512 * rounds - 1) / (512 * rounds);
         per = (per + TILE - 1) / TILE * TILE;
-        if (per < 4 * TILE) per = 4 * TILE;
+        if (per < 8 * TILE) per = 8 * TILE;
         const uint32_t nwg = (uint32_t)((ns + per - 1) / per);
         const bool single = pa.count == 1;
         static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
