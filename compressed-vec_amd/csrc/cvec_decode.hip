@@ -193,40 +193,22 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
 // ------------------------------------------------------------------------------------------------
 // k_sections
 // ------------------------------------------------------------------------------------------------
-constexpr int TILE = 16;            // section slots per chunk (= walker lanes in use)
-// Octet table: one 36-dword row per section (rows are 16-byte aligned and 36 is bank-conflict free
-// for the walker's per-lane rows).  Entries 0..31: byte address of the octet inside the staging slot
-// (16 bits) | nonzero mask (8) | nibble word (8).  Entries 32..35: per-section err, kind, start, length.
-constexpr int OCT_STRIDE = 36;
-constexpr int ROW_ERR = 32, ROW_KIND = 33, ROW_REL = 34, ROW_LEN = 35;
-// Staging slot: 18 KiB = 18 LDS-DMA wave instructions of 1 KiB; holds 16 worst-case u32/f32
-// sections (1100 B) plus the vector headers between them.  Four slots + two tables stay under
-// 80 KiB, so two workgroups share a CU's 160 KiB.
-constexpr int SLOT_PIECES = 18;
-constexpr uint32_t SLOT_BYTES = SLOT_PIECES * 1024;
-constexpr int N_SLOTS = 4;
-static_assert(SLOT_PIECES == 18, "the loader's s_waitcnt vmcnt(18) counts SLOT_PIECES instructions");
+constexpr int TILE = 16; // sections per chunk: one per quad of lanes
+// Staging region of one wave: 18 KiB = 18 LDS-DMA wave instructions of 1 KiB; holds 16 worst-case
+// u32/f32 sections (1100 B) plus the vector headers between them.  Four waves per workgroup, two
+// workgroups per CU: 144 of the CU's 160 KiB.
+constexpr int REGION_PIECES = 18;
+constexpr uint32_t REGION_BYTES = REGION_PIECES * 1024;
+constexpr int SEC_WAVES = 4;
+constexpr int SEC_THREADS = SEC_WAVES * 64;
 
 enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2 };
 
-constexpr int SEC_THREADS = 512; // wave 0 walks, wave 1 plans, wave 7 loads, every wave but 7 decodes
-constexpr int LOADER_WAVE = SEC_THREADS / 64 - 1;
-
-// A chunk = up to TILE consecutive section slots whose bytes fit one staging slot as one span.
-struct ChunkParams {
-    uint64_t s0;      // first section slot
-    uint64_t gbase;   // 16-byte aligned blob offset of the span
-    uint32_t n;       // sections in the chunk (0 = no such chunk)
-    uint32_t nchunks; // 16-byte pieces of the span
-};
-
 struct SecShared {
-    __attribute__((aligned(16))) uint8_t data[N_SLOTS][SLOT_BYTES];
-    __attribute__((aligned(16))) uint32_t octab[2][TILE * OCT_STRIDE];
-    __attribute__((aligned(16))) uint4 meta[8][TILE]; // {0, kind, start inside the slot, length} per section
-    ChunkParams P[8];
-    uint32_t ticket[2];
+    __attribute__((aligned(16))) uint8_t data[SEC_WAVES][REGION_BYTES];
 };
+
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
 
 // One LDS-DMA wave instruction: lane l copies 16 bytes from its own global address to LDS byte
 // address lds_dst + 16*l (lds_dst wave-uniform).  Nothing lands in registers and the compiler does
@@ -241,21 +223,14 @@ __device__ inline void lds_dma16(const void *gsrc, uint32_t lds_dst) {
 }
 
 // Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
-// LDS read here is a naturally aligned dword pair / triple that is then funnel-shifted.
-__device__ inline uint32_t lds_u16_at(const uint8_t *data, uint32_t p) {
-    const uint32_t *q = (const uint32_t *)(data + (p & ~3u));
-    return __builtin_amdgcn_alignbit(q[1], q[0], (p & 3u) << 3) & 0xffffu;
-}
-
-// Inclusive XOR scan over the 32 lanes of each half wave (lane = half*32 + octet), DPP only:
-// shifts by 1, 2, 4, 8 inside a 16-lane row, then lane 15 of rows 0 and 2 into rows 1 and 3.
-__device__ inline uint32_t xor_scan_half(uint32_t x) {
-    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-    x ^= __builtin_amdgcn_update_dpp(0u, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
-    return x;
+// LDS read here is a single byte or naturally aligned dwords that are then funnel-shifted.
+template <int W>
+__device__ inline typename Elem<W>::U lds_load_unaligned(uint32_t addr) {
+    lds_u32p q = (lds_u32p)(uintptr_t)(addr & ~3u);
+    const uint32_t s = (addr & 3u) << 3;
+    if constexpr (W == 4) return __builtin_amdgcn_alignbit(q[1], q[0], s);
+    else return (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
+                ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
 }
 
 template <int ETYPE, bool SINGLE>
@@ -278,336 +253,242 @@ __device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CV
     }
 }
 
-// Decodes two sections of a chunk with one wave: lane = half*32 + o owns octet o (8 consecutive
-// elements) of section sec0 + half.  The octet's header fields are unpacked once per lane; the 8
-// fields of its bitstream are then pulled with one aligned dword-pair read and one funnel shift
-// each (plain bitstream rule of the format, reference src/nibblepacking.rs:436-470,
-// src/nibblepack_simd.rs:571-585), run through the implied XorSink / Delta add and the fused
-// epilogue.  Section kinds are handled by selects, so the two halves may hold different kinds.
-template <int ETYPE, int MODE, bool SINGLE>
-__device__ inline void decode_pair(const uint8_t *data, const uint32_t *octab, uint32_t sec0, uint32_t nsec,
-                                   uint64_t slot0, int lane, const PredArgs &pa, const SinkArgs &sa,
-                                   uint32_t *__restrict__ sec_res, uint8_t *__restrict__ masks,
-                                   void *__restrict__ out_) {
-    constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
-    using U = typename Elem<W>::U;
-    const uint32_t half = (uint32_t)lane >> 5, o = lane & 31;
-    const bool live = sec0 + half < nsec;
-    const uint32_t sec = live ? sec0 + half : sec0;
-    const uint32_t *row = octab + sec * OCT_STRIDE;
-    const uint4 meta = *(const uint4 *)(row + ROW_ERR);
-    uint32_t d = row[o];
-    const uint32_t err = meta.x, kind = meta.y, rel = meta.z;
-    const bool isoct = (kind == K_NP || kind == K_DELTA || kind == K_XOR) && err == 0;
-    const bool isconst = kind == K_CONST, isdelta = kind == K_DELTA;
-    d = isoct ? d : 0u; // mask 0: every element of the lane is zero, reads stay at the buffer start
-
-    // Const value (section byte 1) or Delta base (section byte 4): aligned dwords + funnel shift
-    U v;
-    {
-        const uint32_t a = (isconst || isdelta) ? rel + (isconst ? 1u : 4u) : 0u;
-        const uint32_t *q = (const uint32_t *)(data + (a & ~3u));
-        const uint32_t s = (a & 3u) << 3;
-        if constexpr (W == 4) v = __builtin_amdgcn_alignbit(q[1], q[0], s);
-        else v = (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
-                 ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
+// Exact status of a section whose octet walk ran past its end or met an over-wide octet: the first
+// failing octet in the order of the reference's checks (src/nibblepack_simd.rs:515-557 for 32-bit
+// elements, src/nibblepacking.rs:474-500 for 64-bit): empty input, length < 3, n > 8, payload too
+// long.  Rare path (malformed input only); plain byte reads.
+template <int W>
+__device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, uint32_t end) {
+    for (int k = 0; k < FIXED_LEN / 8; k++) {
+        const int rem = (int)end - (int)p;
+        if (rem <= 0) return CVEC_NOT_ENOUGH_SPACE;
+        const uint32_t mask = data[p];
+        if (mask == 0) { p += 1; continue; }
+        if (W == 4 && rem < 3) return CVEC_NOT_ENOUGH_SPACE;
+        if (rem < 2) return CVEC_NOT_ENOUGH_SPACE;
+        const uint32_t hn = (uint32_t)data[p + 1] >> 4;
+        if (W == 4 && hn > 7) return CVEC_INVALID_FORMAT;
+        const int size = (int)(2 + (((hn + 1) * __popc(mask) + 1) >> 1));
+        if (size > rem) return CVEC_NOT_ENOUGH_SPACE;
+        p += size;
     }
-
-    // ---- the lane's octet ---------------------------------------------------------------------------
-    const uint32_t mask = (d >> 16) & 0xffu, hn = d >> 28;
-    const uint32_t n4 = (hn << 2) + 4u;          // field width in bits
-    const uint32_t t4 = (d >> 22) & 0x3cu;       // trailing zero bits
-    uint32_t pb = ((d & 0xffffu) << 3) + 16u;    // bit position of the next stored field
-    U x[8];
-    if constexpr (W == 4) {
-        // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
-        const uint32_t fm = t4 >= 32u ? 0u : 0xffffffffu >> (32u - n4);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t sm = (uint32_t)((int32_t)(mask << (31 - k)) >> 31); // all ones iff element k is stored
-            const uint32_t *q = (const uint32_t *)(data + ((pb >> 3) & ~3u));
-            const uint32_t f = __builtin_amdgcn_alignbit(q[1], q[0], pb);       // uses pb & 31
-            x[k] = ((f & fm) << (t4 & 31u)) & sm;
-            pb += n4 & sm;
-        }
-    } else {
-        const uint64_t fm = ~0ull >> (64u - n4);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t sm = (uint32_t)((int32_t)(mask << (31 - k)) >> 31);
-            const uint32_t *q = (const uint32_t *)(data + ((pb >> 3) & ~3u));
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-            const uint64_t f = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, pb) |
-                               ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, pb) << 32);
-            x[k] = ((f & fm) << t4) & (uint64_t)(int64_t)(int32_t)sm;
-            pb += n4 & sm;
-        }
-    }
-    if constexpr (ETYPE == CVEC_F32) {
-        // XorSink: out[i] = out[i-8] ^ x[i], state zero at the section start (src/sink.rs:271-275,
-        // src/section.rs:707): per element index k an inclusive scan over the section's 32 octets.
-#pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = xor_scan_half((uint32_t)x[k]);
-    } else {
-        // AddConstSink(base) around the octet decode of a Delta section (src/section.rs:636-641), wrapping
-        const U base = isdelta ? v : (U)0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) x[k] += base;
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = isconst ? v : x[k];
-
-    // ---- per-section status ----------------------------------------------------------------------------
-    uint32_t status = err;
-    if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
-    if constexpr (W == 4) {
-        // a stored octet of a 32-bit section claiming more than 8 nibbles (src/nibblepack_simd.rs:541):
-        // every octet before it fitted, so it is the section's first error
-        const unsigned long long wide = __ballot(mask != 0 && hn > 7);
-        if (((uint32_t)(half ? wide >> 32 : wide)) != 0 && status == 0) status = CVEC_INVALID_FORMAT;
-    }
-    const bool skip = kind == K_SKIP;
-    const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
-    const bool ok = live && !skip && status == 0;
-    uint32_t count;
-    if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
-        uint32_t c_lo = 0, c_hi = 0, mbyte = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const bool m = pred_match<ETYPE, SINGLE>(pa, x[k]);
-            const unsigned long long b = __ballot(m);
-            c_lo += __popc((uint32_t)b);
-            c_hi += __popc((uint32_t)(b >> 32));
-            if constexpr (MODE == MODE_FILTER_MASKS) mbyte |= m ? (1u << k) : 0u;
-        }
-        count = half ? c_hi : c_lo;
-        if (zeroes) { // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
-            count = pa.match_zero ? FIXED_LEN : 0;
-            mbyte = pa.match_zero ? 0xffu : 0u;
-        }
-        if constexpr (MODE == MODE_FILTER_MASKS) {
-            if (ok) masks[(slot0 + half) * 32 + o] = (uint8_t)mbyte;
-        }
-    } else {
-        if (sa.add_const) {
-            // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards the
-            // base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
-            if constexpr (ETYPE == CVEC_F32) {
-                const float bf = __uint_as_float((uint32_t)sa.base);
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    x[k] = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x[k]) + bf);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; k++) x[k] += (U)sa.base;
-            }
-        }
-        if (ok) {
-            // 8 consecutive elements per lane, lanes consecutive: full-line stores
-            U *op = (U *)out_ + (slot0 + half) * FIXED_LEN + 8 * o;
-            if constexpr (W == 4) {
-                ((uint4 *)op)[0] = make_uint4(x[0], x[1], x[2], x[3]);
-                ((uint4 *)op)[1] = make_uint4(x[4], x[5], x[6], x[7]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    ((uint4 *)op)[k] = make_uint4((uint32_t)x[2 * k], (uint32_t)(x[2 * k] >> 32),
-                                                  (uint32_t)x[2 * k + 1], (uint32_t)(x[2 * k + 1] >> 32));
-            }
-        }
-        count = FIXED_LEN;
-    }
-    if (live && o == 0) sec_res[slot0 + half] = skip ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
+    return 0;
 }
 
-// The octet walk of one section by one lane: 32 dependent steps.  A step's critical chain is one
-// LDS round trip (two byte reads, always aligned) and eight VALU operations ending in the next
-// cursor; the reads of the next octet are issued as soon as that cursor is known, and the table
-// entry of the current octet is packed and stored in the shadow of their latency.  Branch-free; a
-// lone wave issues one VALU operation per ~4 cycles, so every instruction in the chain is paid 32
-// times.  The loop only notices a cursor that ends past the section; the exact status of the first
-// failing octet is worked out afterwards.  After an error the cursor keeps moving over garbage
-// (reads stay inside the workgroup's LDS allocation or return 0); the error decides the section's
-// result.  An octet of a 32-bit section claiming more than 8 nibbles is left to the decoder, which
-// sees every octet header anyway (the walk itself does not depend on it).
-template <int W>
-__device__ __forceinline__ void walk_section(const uint8_t *data, uint32_t *row) {
-    const uint32_t kind = row[ROW_KIND];
-    if (!(kind == K_NP || kind == K_DELTA || kind == K_XOR)) return;
-    const uint32_t rel = row[ROW_REL];
-    const uint32_t end = rel + row[ROW_LEN];
-    uint32_t p = rel + (kind == K_DELTA ? DELTA_HDR : 3);
-    // same cursor as a raw LDS byte address, advanced beside p (not behind it)
-    uint32_t pa = (uint32_t)(uintptr_t)data + p;
-    // Two separate byte reads (hipcc would merge plain C byte loads into one 16-bit read, which at
-    // an odd address takes the slow misaligned-LDS path).
+// One chunk (up to 16 sections staged in the wave's LDS region) by one wave.  Lane = 4*sec + q: the
+// four lanes of a quad walk the octets of section `sec` together (same addresses: LDS broadcasts)
+// and lane q extracts elements 2q and 2q+1 of every octet, so nothing has to cross lanes and no
+// octet table is needed.  A step of the loop handles octet k of all 16 sections:
+//   - the walk chain: two byte reads (always aligned), octet size, next cursor; the reads of the
+//     next octet are issued as soon as the cursor is known,
+//   - in the shadow of that latency the two fields of the current octet are pulled out of the
+//     bitstream with aligned dword reads and funnel shifts (plain bitstream rule of the format,
+//     reference src/nibblepacking.rs:436-470, src/nibblepack_simd.rs:571-585), run through the
+//     XorSink state (kept in registers: octet k of a lane XORs onto octet k-1 of the same lane,
+//     src/sink.rs:271-275, src/section.rs:707) or the Delta base add (src/section.rs:636-641) and
+//     the fused epilogue.
+// Section kinds are folded into the same loop: a Null or Const section runs it with every mask
+// forced to 0 and its value preloaded into the XOR state / the base.
+template <int ETYPE, int MODE, bool SINGLE>
+__device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
+                                              uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
+                                              const SinkArgs &sa, uint32_t *__restrict__ sec_res,
+                                              uint8_t *__restrict__ masks, void *__restrict__ out_) {
+    constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
+    using U = typename Elem<W>::U;
+    const uint32_t q = lane & 3;
+    const bool isoct = live && (kind == K_NP || kind == K_DELTA || kind == K_XOR);
+    const bool isconst = live && kind == K_CONST, isdelta = live && kind == K_DELTA;
+    const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
+    const uint32_t end = rel + len;
+    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : 3u) : 0u;
+    const uint32_t octmask = isoct ? 0xffu : 0u;
+    // Const value (section byte 1) or Delta base (section byte 4)
+    U v = 0;
+    if (isconst || isdelta) v = lds_load_unaligned<W>(lds_base + rel + (isconst ? 1u : 4u));
+    U st0 = 0, st1 = 0; // XOR state of the lane's two element columns / the additive base
+    if constexpr (ETYPE == CVEC_F32) { st0 = st1 = isconst ? v : (U)0; }
+    const U base = (isconst || isdelta) ? v : (U)0;
+    const uint32_t lowmask = (1u << (2 * q)) - 1u;
+    uint32_t cnt = 0, hmax = 0;
+    U *op = (U *)out_ + slot * FIXED_LEN + 2 * q;
+    const bool addc = sa.add_const != 0;
+
+    uint32_t pa_ = lds_base + p0;
     uint32_t mask, nw;
     asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(mask), "=&v"(nw)
-                 : "v"(pa)
+                 : "v"(pa_)
                  : "memory");
-#pragma unroll 8
+#pragma unroll 4
     for (int k = 0; k < FIXED_LEN / 8; k++) {
-        // octet bytes: 1 if mask == 0, else 2 + (n*cnt + 1)/2  ==  (hn*cnt + cnt + 2 + 3*[mask != 0]) >> 1
+        mask &= octmask;
+        // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2 ----------------------------
         const uint32_t hn = nw >> 4; // n - 1
-        const uint32_t cnt = __popc(mask);
-        const uint32_t a = (uint32_t)__umul24(min(mask, 1u), 3u) + (cnt + 2u);
-        const uint32_t size = ((uint32_t)__umul24(hn, cnt) + a) >> 1;
-        pa += size;
-        // Reads of the next octet (after the last one: a harmless read of the byte that follows).
-        // mask and nw pass through the statement so that the packing below is scheduled behind it.
+        const uint32_t pc = __popc(mask);
+        const uint32_t a3 = (uint32_t)__umul24(min(mask, 1u), 3u) + (pc + 2u);
+        const uint32_t size = ((uint32_t)__umul24(hn, pc) + a3) >> 1;
+        const uint32_t pa_cur = pa_;
+        pa_ += size;
+        // reads of the next octet (after the last one: a harmless read of the bytes that follow);
+        // mask and nw pass through the statement so that the decode below is scheduled behind it
         uint32_t mask_n, nw_n;
         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1"
                      : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
-                     : "v"(pa)
+                     : "v"(pa_)
                      : "memory");
-        row[k] = p | (mask << 16) | (nw << 24); // nw is don't-care when mask == 0
-        p += size;
+        if constexpr (W == 4) hmax = max(hmax, mask ? hn : 0u);
+        // ---- the lane's two fields of the current octet ------------------------------------------------------
+        const uint32_t n4 = (hn << 2) + 4u;       // field width in bits
+        const uint32_t t4 = (nw & 15u) << 2;      // trailing zero bits
+        const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
+        const uint32_t A = pa_cur + 2u + (b0 >> 3);
+        const uint32_t s = (A << 3) | (b0 & 4u);  // funnel shift; only bits 4:0 are used
+        lds_u32p qd = (lds_u32p)(uintptr_t)(A & ~3u);
+        const uint32_t sm0 = (uint32_t)((int32_t)(mask << (31 - 2 * q)) >> 31); // all ones iff element 2q is stored
+        const uint32_t sm1 = (uint32_t)((int32_t)(mask << (30 - 2 * q)) >> 31);
+        U x0, x1;
+        if constexpr (W == 4) {
+            const uint32_t d0 = qd[0], d1 = qd[1], d2 = qd[2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s), hi = __builtin_amdgcn_alignbit(d2, d1, s);
+            // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
+            const uint32_t fm = t4 >= 32u ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
+            const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> (n4 & sm0));
+            x0 = ((lo & fm) & sm0) << (t4 & 31u);
+            x1 = ((w1 & fm) & sm1) << (t4 & 31u);
+        } else {
+            const uint32_t d0 = qd[0], d1 = qd[1], d2 = qd[2], d3 = qd[3], d4 = qd[4];
+            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, s), w1 = __builtin_amdgcn_alignbit(d2, d1, s),
+                           w2 = __builtin_amdgcn_alignbit(d3, d2, s), w3 = __builtin_amdgcn_alignbit(d4, d3, s);
+            const uint64_t fm = ~0ull >> ((64u - n4) & 63u);
+            const uint64_t f0 = ((uint64_t)w1 << 32) | w0;
+            // second field: n4 bits further on if the first one is stored (n4 up to 64)
+            const unsigned __int128 win = ((unsigned __int128)(((uint64_t)w3 << 32) | w2) << 64) | f0;
+            const uint64_t f1 = (uint64_t)(win >> (n4 & sm0));
+            x0 = ((f0 & fm) & (uint64_t)(int64_t)(int32_t)sm0) << t4;
+            x1 = ((f1 & fm) & (uint64_t)(int64_t)(int32_t)sm1) << t4;
+        }
+        if constexpr (ETYPE == CVEC_F32) {
+            st0 ^= x0; st1 ^= x1;
+            x0 = st0; x1 = st1;
+        } else {
+            x0 += base; x1 += base;
+        }
+        // ---- epilogue ----------------------------------------------------------------------------------------
+        if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
+            const bool m0 = pred_match<ETYPE, SINGLE>(pa, x0), m1 = pred_match<ETYPE, SINGLE>(pa, x1);
+            cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
+            if constexpr (MODE == MODE_FILTER_MASKS) {
+                // byte k of the section's mask: bits 2q, 2q+1 from each lane of the quad
+                uint32_t bits = zeroes ? (pa.match_zero ? 3u : 0u) : ((m0 ? 1u : 0u) | (m1 ? 2u : 0u));
+                bits <<= 2 * q;
+                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+                if (live && q == 0 && kind != K_SKIP && kind != K_ILLEGAL) masks[slot * 32 + k] = (uint8_t)bits;
+            }
+        } else {
+            if (addc) {
+                // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards the
+                // base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
+                if constexpr (ETYPE == CVEC_F32) {
+                    const float bf = __uint_as_float((uint32_t)sa.base);
+                    x0 = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x0) + bf);
+                    x1 = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x1) + bf);
+                } else {
+                    x0 += (U)sa.base; x1 += (U)sa.base;
+                }
+            }
+            if (live && kind != K_SKIP && kind != K_ILLEGAL) {
+                if constexpr (W == 4) *(uint2 *)(op + 8 * k) = make_uint2(x0, x1);
+                else *(uint4 *)(op + 8 * k) = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mask_n), "+v"(nw_n) : : "memory");
         mask = mask_n;
         nw = nw_n;
     }
-    // Common case: the cursor ended inside the section.
-    uint32_t err = 0;
-    if (p > end) {
-        // exact status of the first failing octet, in the order of the reference's checks
-        // (src/nibblepack_simd.rs:515-557): empty, length < 3, n > 8, payload too long
-        for (int k = 0; k < FIXED_LEN / 8 && !err; k++) {
-            const uint32_t e = row[k];
-            const uint32_t pk = e & 0xffffu, mk = (e >> 16) & 0xffu, hn = e >> 28;
-            const int rem = (int)end - (int)pk;
-            const int size = mk ? (int)(2 + (((hn + 1) * __popc(mk) + 1) >> 1)) : 1;
-            if (rem <= 0) err = CVEC_NOT_ENOUGH_SPACE;
-            else if (mk) {
-                if (W == 4 && rem < 3) err = CVEC_NOT_ENOUGH_SPACE;
-                else if (W == 4 && hn > 7) err = CVEC_INVALID_FORMAT;
-                else if (size > rem || rem < 2) err = CVEC_NOT_ENOUGH_SPACE;
-            }
-        }
+    // ---- per-section result ------------------------------------------------------------------------------------
+    uint32_t status = 0;
+    if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
+    const uint32_t p_end = pa_ - lds_base;
+    if (isoct && (p_end > end || (W == 4 && hmax > 7))) status = walk_status<W>(data, p0, end);
+    uint32_t count;
+    if constexpr (MODE == MODE_DECODE) {
+        count = FIXED_LEN;
+    } else {
+        cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+        cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+        // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
+        count = zeroes ? (pa.match_zero ? FIXED_LEN : 0) : cnt;
     }
-    row[ROW_ERR] = err;
+    if (live && q == 0)
+        sec_res[slot] = kind == K_SKIP ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
 }
 
-// k_sections: persistent workgroups, each owning a contiguous range of section slots, run a
-// five-stage software pipeline over chunks of that range with ONE barrier per step.  In step t:
-//     wave 1     plans chunk t (extent from the descriptors)
-//     wave 0     walks the octets of chunk t-3
-//     wave 7     issues the LDS-DMA loads of chunk t-1 into the slot chunk t-5 vacated and waits until
-//                chunk t-2 has landed; it does nothing else, so a full memory queue stalls only it
-//     all but 7  decode chunk t-4, drawing section pairs from a ticket counter (waves 0 and 1
-//                join when their own job is done)
-// A chunk's bytes therefore have two whole steps to arrive, the blob streams at a steady rate
-// whatever the compute waves do, and the serial octet walk of one chunk runs beside the decode of
-// another.
+// k_sections: every wave is on its own.  A wave owns a contiguous range of section slots and an
+// 18 KiB staging region in LDS, and loops over chunks of up to 16 sections: plan the chunk's span
+// from the descriptors, copy it into the region with LDS-DMA loads (no registers involved), fetch
+// the next chunk's descriptors meanwhile, wait, then walk and decode the 16 sections at once
+// (process_chunk).  No barriers and no cross-wave traffic: while one wave waits for its bytes the
+// other waves of the CU (8 in all, two per SIMD) compute, which keeps both the memory queue and
+// the vector units fed.
 template <int ETYPE, int MODE, bool SINGLE>
-__global__ __launch_bounds__(SEC_THREADS, 4) void k_sections(const uint8_t *__restrict__ bytes,
+__global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
-                                                          uint64_t sections_per_wg, PredArgs pa, SinkArgs sa,
+                                                          uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
                                                           uint32_t *__restrict__ sec_res,
                                                           uint8_t *__restrict__ masks, void *__restrict__ out_) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared sm;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t sA = (uint64_t)blockIdx.x * sections_per_wg;
-    const uint64_t sB = sA + sections_per_wg < n_sections ? sA + sections_per_wg : n_sections;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t sA = ((uint64_t)blockIdx.x * SEC_WAVES + wave) * sections_per_wave;
+    const uint64_t sB = sA + sections_per_wave < n_sections ? sA + sections_per_wave : n_sections;
     if (sA >= sB) return;
+    const uint8_t *data = sm.data[wave];
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)data);
+    const uint32_t sec = (uint32_t)lane >> 2;
 
-    // planning state, meaningful in wave 1 only (lanes 0..TILE-1 hold one descriptor each)
     auto load_desc = [&](uint64_t s) -> uint64_t {
-        return (lane < TILE && s + (uint64_t)lane < sB) ? desc[s + lane] : desc_pack(0, 0, K_SKIP);
+        return s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
     };
-    auto clip_len = [](uint64_t d) -> uint32_t {
-        const uint32_t len = desc_len(d);
-        return len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
-    };
-    uint64_t d_cur = desc_pack(0, 0, K_SKIP), s_cur = sA;
-    // Two workgroups share a CU and wave w of a workgroup runs on SIMD w % 4: the latency-critical
-    // walkers of co-resident workgroups (block ids 256 apart in dispatch order) go to different SIMDs.
-    const int walker_wave = ((blockIdx.x >> 8) & 1) * 2, planner_wave = walker_wave + 1;
-    if (wave == planner_wave) d_cur = load_desc(sA);
-
-    for (uint32_t t = 0;; t++) {
-        if (wave == planner_wave) {
-            // ---- plan chunk t: longest run of sections from s_cur whose span fits a slot ---------------
-            const uint64_t left = s_cur < sB ? sB - s_cur : 0;
-            const int avail = (int)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
-            const uint64_t off = desc_off(d_cur);
-            const uint64_t gb = __shfl(off, 0, 64) & ~15ull;
-            const uint32_t len = clip_len(d_cur);
-            const uint64_t endl = off + len - gb; // wraps to a huge value if off < gb
-            const bool fits = lane >= avail || endl <= (uint64_t)SLOT_BYTES;
-            const unsigned long long m = __ballot(fits);
-            int n = m == ~0ull ? avail : __builtin_ctzll(~m);
-            n = n < avail ? n : avail;
-            uint32_t e = lane < n ? (uint32_t)endl : 0u;
+    uint64_t d_cur = load_desc(sA);
+    for (uint64_t s_cur = sA; s_cur < sB;) {
+        // ---- plan: longest run of sections from s_cur whose span fits the region ----------------------------
+        const uint64_t left = sB - s_cur;
+        const uint32_t avail = (uint32_t)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
+        const uint64_t off = desc_off(d_cur);
+        const uint64_t gb = __shfl(off, 0, 64) & ~15ull;
+        uint32_t len = desc_len(d_cur);
+        len = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
+        const uint64_t endl = off + len - gb; // wraps to a huge value if off < gb
+        const bool fits = sec >= avail || endl <= (uint64_t)REGION_BYTES;
+        const unsigned long long m = __ballot(fits);
+        uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> 2;
+        n = n < avail ? n : avail;
+        uint32_t e = sec < n ? (uint32_t)endl : 0u;
 #pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(e, d, 64); e = o > e ? o : e; }
-            if (lane == 0) {
-                ChunkParams cp;
-                cp.s0 = s_cur; cp.gbase = gb; cp.n = (uint32_t)n; cp.nchunks = (e + 15) >> 4;
-                sm.P[t & 7] = cp;
-                sm.ticket[(t + 1) & 1] = 0; // counter of chunk t-3, decoded in the next step
-            }
-            if (lane < n) sm.meta[t & 7][lane] = make_uint4(0u, desc_kind(d_cur), (uint32_t)(off - gb), len);
-            // descriptors of chunk t+1 start where chunk t ends
-            s_cur += (uint64_t)n;
-            d_cur = load_desc(s_cur);
-        } else if (wave == walker_wave) {
-            // ---- walk chunk t-3 -----------------------------------------------------------------------
-            if (t >= 3 && sa._pad != 1) {
-                const uint32_t nw = sm.P[(t - 3) & 7].n;
-                if ((uint32_t)lane < nw) {
-                    uint32_t *row = sm.octab[(t - 3) & 1] + lane * OCT_STRIDE;
-                    *(uint4 *)(row + ROW_ERR) = sm.meta[(t - 3) & 7][lane];
-                    __builtin_amdgcn_s_setprio(3); // the other waves will wait on this chain at the barrier
-                    walk_section<W>(sm.data[(t - 3) & 3], row);
-                    __builtin_amdgcn_s_setprio(0);
-                }
-            }
-        } else if (wave == LOADER_WAVE) {
-            // ---- LDS-DMA loads of chunk t-1; afterwards everything but those has landed ------------------
-            uint32_t nch = 0;
-            ChunkParams cp;
-            if (t >= 1) {
-                cp = sm.P[(t - 1) & 7];
-                nch = __builtin_amdgcn_readfirstlane(cp.n) ? __builtin_amdgcn_readfirstlane(cp.nchunks) : 0u;
-            }
-            if (nch && sa._pad != 3) {
-                const uint8_t *src = bytes + cp.gbase;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)&sm.data[(t - 1) & 3][0]);
-#pragma unroll
-                for (int i = 0; i < SLOT_PIECES; i++) {
-                    const uint32_t c = (uint32_t)lane + 64u * i;
-                    // always SLOT_PIECES instructions (the wait below counts them); lanes past the
-                    // span re-read piece 0
-                    lds_dma16(src + 16ull * (c < nch ? c : 0u), dst + 1024u * i);
-                }
-                asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int d = 32; d >= 4; d >>= 1) { uint32_t o = __shfl_xor(e, d, 64); e = o > e ? o : e; }
+        const uint32_t nch = __builtin_amdgcn_readfirstlane((e + 15) >> 4); // 16-byte pieces of the span
+        // ---- stage: LDS-DMA, 1 KiB per instruction ------------------------------------------------------------
+        if (sa._pad != 3) {
+            const uint8_t *src = bytes + gb;
+            for (uint32_t i = 0; i * 64 < nch; i++) {
+                const uint32_t c = i * 64 + (uint32_t)lane;
+                lds_dma16(src + 16ull * (c < nch ? c : nch - 1), lds_base + 1024u * i); // lanes past the span re-read its last piece
             }
         }
-        // ---- decode chunk t-4: section pairs by ticket, the next ticket fetched while a pair decodes ------
-        if (wave != LOADER_WAVE && t >= 4 && sa._pad == 0) {
-            const ChunkParams cp = sm.P[(t - 4) & 7];
-            const uint32_t nd = __builtin_amdgcn_readfirstlane(cp.n);
-            const uint32_t npairs = (nd + 1) >> 1;
-            uint32_t *tk = &sm.ticket[(t - 4) & 1];
-            uint32_t nxt = 0;
-            if (lane == 0) nxt = atomicAdd(tk, 1u);
-            nxt = __builtin_amdgcn_readfirstlane(nxt);
-            while (nxt < npairs) {
-                const uint32_t cur = nxt;
-                if (lane == 0) nxt = atomicAdd(tk, 1u);
-                decode_pair<ETYPE, MODE, SINGLE>(sm.data[(t - 4) & 3], sm.octab[(t - 4) & 1], 2 * cur, nd,
-                                                 cp.s0 + 2 * cur, lane, pa, sa, sec_res, masks, out_);
-                nxt = __builtin_amdgcn_readfirstlane(nxt);
-            }
-        }
-        __syncthreads();
-        if (t >= 4 && sm.P[(t - 4) & 7].n == 0) break; // chunk t-4 does not exist: nothing is in flight any more
+        // descriptors of the next chunk, in flight beside the DMA
+        const uint64_t s_next = s_cur + n;
+        const uint64_t d_next = load_desc(s_next);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- walk + decode ----------------------------------------------------------------------------------------
+        if (sa._pad != 1)
+            process_chunk<ETYPE, MODE, SINGLE>(data, lds_base, sec < n ? desc_kind(d_cur) : K_SKIP, (uint32_t)(off - gb),
+                                               len, sec < n, s_cur + sec, lane, pa, sa, sec_res, masks, out_);
+        s_cur = s_next;
+        d_cur = d_next;
     }
 }
 
@@ -748,15 +629,19 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
     if (ns > 0) {
         // Persistent workgroups: two fit a CU (LDS), so 2 x 256 x 2 rounds; each owns a contiguous
         // range of section slots (a multiple of TILE) and pipelines over it.
-        static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 2; }();
-        uint64_t per = (ns + 512 * rounds - 1) / (512 * rounds);
+        // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
+        // range of section slots (a multiple of TILE).
+        static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 1; }();
+        const uint64_t nwaves_max = 256ull * 2 * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
+        uint64_t per = (ns + nwaves_max - 1) / nwaves_max;
         per = (per + TILE - 1) / TILE * TILE;
-        if (per < 8 * TILE) per = 8 * TILE;
-        const uint32_t nwg = (uint32_t)((ns + per - 1) / per);
+        if (per < 2 * TILE) per = 2 * TILE;
+        const uint64_t nwaves = (ns + per - 1) / per;
+        const uint32_t nwg = (uint32_t)((nwaves + SEC_WAVES - 1) / SEC_WAVES);
         const bool single = pa.count == 1;
         static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
         SinkArgs sa2 = sa;
-        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage only, 2 = stage + walk
+        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage only, 3 = compute only
 #define CVEC_LAUNCH_SEC(M, S)                                                                                       \
     k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
         if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);
