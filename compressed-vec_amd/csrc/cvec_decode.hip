@@ -199,6 +199,9 @@ constexpr int TILE = 16; // sections per chunk: one per quad of lanes
 // workgroups per CU: 144 of the CU's 160 KiB.
 constexpr int REGION_PIECES = 18;
 constexpr uint32_t REGION_BYTES = REGION_PIECES * 1024;
+// The last 64 bytes of a region stay zero: sections without octets (Null, Const, skipped slots) run
+// the octet loop over them (32 empty octets), which keeps the loop free of per-kind masking.
+constexpr uint32_t REGION_SPAN = REGION_BYTES - 64;
 constexpr int SEC_WAVES = 4;
 constexpr int SEC_THREADS = SEC_WAVES * 64;
 
@@ -209,18 +212,6 @@ struct SecShared {
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
-
-// One LDS-DMA wave instruction: lane l copies 16 bytes from its own global address to LDS byte
-// address lds_dst + 16*l (lds_dst wave-uniform).  Nothing lands in registers and the compiler does
-// not count it: completion is waited for with an explicit s_waitcnt vmcnt.  M0 (the LDS base of the
-// instruction) is saved and restored inside the statement.
-__device__ inline void lds_dma16(const void *gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
 
 // Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
 // LDS read here is a single byte or naturally aligned dwords that are then funnel-shifted.
@@ -289,8 +280,13 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
 //     the fused epilogue.
 // Section kinds are folded into the same loop: a Null or Const section runs it with every mask
 // forced to 0 and its value preloaded into the XOR state / the base.
-template <int ETYPE, int MODE, bool SINGLE>
-__device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
+//
+// CAREFUL = false is the common path: it assumes that no stored octet of a 32-bit section claims
+// more than 8 nibbles or 8 or more trailing zero nibbles (never produced by an encoder: the value
+// would not fit 32 bits) and only records whether one did; the caller then repeats the chunk with
+// CAREFUL = true, which handles both exactly.  Returns that record.
+template <int ETYPE, int MODE, bool SINGLE, bool CAREFUL>
+__device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t *__restrict__ sec_res,
                                               uint8_t *__restrict__ masks, void *__restrict__ out_) {
@@ -301,8 +297,7 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
     const bool isconst = live && kind == K_CONST, isdelta = live && kind == K_DELTA;
     const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
     const uint32_t end = rel + len;
-    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : 3u) : 0u;
-    const uint32_t octmask = isoct ? 0xffu : 0u;
+    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : 3u) : REGION_SPAN;
     // Const value (section byte 1) or Delta base (section byte 4)
     U v = 0;
     if (isconst || isdelta) v = lds_load_unaligned<W>(lds_base + rel + (isconst ? 1u : 4u));
@@ -310,7 +305,8 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
     if constexpr (ETYPE == CVEC_F32) { st0 = st1 = isconst ? v : (U)0; }
     const U base = (isconst || isdelta) ? v : (U)0;
     const uint32_t lowmask = (1u << (2 * q)) - 1u;
-    uint32_t cnt = 0, hmax = 0;
+    uint32_t cnt = 0, hmax = 0, racc = 0;
+    const uint32_t q2 = 2 * q;
     U *op = (U *)out_ + slot * FIXED_LEN + 2 * q;
     const bool addc = sa.add_const != 0;
 
@@ -322,7 +318,6 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
                  : "memory");
 #pragma unroll 4
     for (int k = 0; k < FIXED_LEN / 8; k++) {
-        mask &= octmask;
         // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2 ----------------------------
         const uint32_t hn = nw >> 4; // n - 1
         const uint32_t pc = __popc(mask);
@@ -337,7 +332,7 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
                      : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
                      : "v"(pa_)
                      : "memory");
-        if constexpr (W == 4) hmax = max(hmax, mask ? hn : 0u);
+        if constexpr (W == 4 && CAREFUL) hmax = max(hmax, mask ? hn : 0u);
         // ---- the lane's two fields of the current octet ------------------------------------------------------
         const uint32_t n4 = (hn << 2) + 4u;       // field width in bits
         const uint32_t t4 = (nw & 15u) << 2;      // trailing zero bits
@@ -345,14 +340,15 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
         const uint32_t A = pa_cur + 2u + (b0 >> 3);
         const uint32_t s = (A << 3) | (b0 & 4u);  // funnel shift; only bits 4:0 are used
         lds_u32p qd = (lds_u32p)(uintptr_t)(A & ~3u);
-        const uint32_t sm0 = (uint32_t)((int32_t)(mask << (31 - 2 * q)) >> 31); // all ones iff element 2q is stored
-        const uint32_t sm1 = (uint32_t)((int32_t)(mask << (30 - 2 * q)) >> 31);
+        const uint32_t sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
+        const uint32_t sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
+        if constexpr (W == 4 && !CAREFUL) racc |= nw & (sm0 | sm1); // the quad's lanes cover every stored element
         U x0, x1;
         if constexpr (W == 4) {
             const uint32_t d0 = qd[0], d1 = qd[1], d2 = qd[2];
             const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s), hi = __builtin_amdgcn_alignbit(d2, d1, s);
             // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
-            const uint32_t fm = t4 >= 32u ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
+            const uint32_t fm = (CAREFUL && t4 >= 32u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
             const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> (n4 & sm0));
             x0 = ((lo & fm) & sm0) << (t4 & 31u);
             x1 = ((w1 & fm) & sm1) << (t4 & 31u);
@@ -411,7 +407,7 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
     uint32_t status = 0;
     if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
     const uint32_t p_end = pa_ - lds_base;
-    if (isoct && (p_end > end || (W == 4 && hmax > 7))) status = walk_status<W>(data, p0, end);
+    if (isoct && (p_end > end || (W == 4 && CAREFUL && hmax > 7))) status = walk_status<W>(data, p0, end);
     uint32_t count;
     if constexpr (MODE == MODE_DECODE) {
         count = FIXED_LEN;
@@ -423,15 +419,27 @@ __device__ __forceinline__ void process_chunk(const uint8_t *data, uint32_t lds_
     }
     if (live && q == 0)
         sec_res[slot] = kind == K_SKIP ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
+    return isoct && (racc & 0x88u) != 0;
 }
 
+// Plan of one chunk: the longest run of sections from s whose span fits a staging region.
+struct ChunkPlan {
+    uint64_t gb;   // 16-byte aligned blob offset of the span
+    uint32_t n;    // sections in the chunk
+    uint32_t nch;  // 16-byte pieces of the span
+    uint32_t rel;  // the lane's section: start inside the region,
+    uint32_t len;  //   clipped length,
+    uint32_t kind; //   kind (K_SKIP beyond the chunk)
+};
+
 // k_sections: every wave is on its own.  A wave owns a contiguous range of section slots and an
-// 18 KiB staging region in LDS, and loops over chunks of up to 16 sections: plan the chunk's span
-// from the descriptors, copy it into the region with LDS-DMA loads (no registers involved), fetch
-// the next chunk's descriptors meanwhile, wait, then walk and decode the 16 sections at once
-// (process_chunk).  No barriers and no cross-wave traffic: while one wave waits for its bytes the
-// other waves of the CU (8 in all, two per SIMD) compute, which keeps both the memory queue and
-// the vector units fed.
+// 18 KiB staging region in LDS, and loops over chunks of up to 16 sections.  Per chunk: the bytes
+// prefetched into registers during the previous chunk's compute are written to the region; the next
+// chunk is planned from its descriptors and its global loads are issued into those registers (plus
+// the descriptor loads of the chunk after it); then the 16 sections are walked and decoded at once
+// (process_chunk) while the loads fly.  Registers, not a second LDS region, double-buffer the
+// stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
+// No barriers and no cross-wave traffic.
 template <int ETYPE, int MODE, bool SINGLE>
 __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
@@ -446,49 +454,83 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     const uint64_t sA = ((uint64_t)blockIdx.x * SEC_WAVES + wave) * sections_per_wave;
     const uint64_t sB = sA + sections_per_wave < n_sections ? sA + sections_per_wave : n_sections;
     if (sA >= sB) return;
-    const uint8_t *data = sm.data[wave];
+    uint8_t *data = sm.data[wave];
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)data);
     const uint32_t sec = (uint32_t)lane >> 2;
 
     auto load_desc = [&](uint64_t s) -> uint64_t {
         return s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
     };
-    uint64_t d_cur = load_desc(sA);
-    for (uint64_t s_cur = sA; s_cur < sB;) {
-        // ---- plan: longest run of sections from s_cur whose span fits the region ----------------------------
-        const uint64_t left = sB - s_cur;
+    auto plan = [&](uint64_t s, uint64_t d) -> ChunkPlan {
+        ChunkPlan c;
+        const uint64_t left = s < sB ? sB - s : 0;
         const uint32_t avail = (uint32_t)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
-        const uint64_t off = desc_off(d_cur);
-        const uint64_t gb = __shfl(off, 0, 64) & ~15ull;
-        uint32_t len = desc_len(d_cur);
-        len = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
-        const uint64_t endl = off + len - gb; // wraps to a huge value if off < gb
-        const bool fits = sec >= avail || endl <= (uint64_t)REGION_BYTES;
+        const uint64_t off = desc_off(d);
+        c.gb = __shfl(off, 0, 64) & ~15ull;
+        uint32_t len = desc_len(d);
+        c.len = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
+        const uint64_t endl = off + c.len - c.gb; // wraps to a huge value if off < gb
+        const bool fits = sec >= avail || endl <= (uint64_t)REGION_SPAN;
         const unsigned long long m = __ballot(fits);
         uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> 2;
-        n = n < avail ? n : avail;
-        uint32_t e = sec < n ? (uint32_t)endl : 0u;
+        c.n = n < avail ? n : avail;
+        uint32_t e = sec < c.n ? (uint32_t)endl : 0u;
 #pragma unroll
-        for (int d = 32; d >= 4; d >>= 1) { uint32_t o = __shfl_xor(e, d, 64); e = o > e ? o : e; }
-        const uint32_t nch = __builtin_amdgcn_readfirstlane((e + 15) >> 4); // 16-byte pieces of the span
-        // ---- stage: LDS-DMA, 1 KiB per instruction ------------------------------------------------------------
-        if (sa._pad != 3) {
-            const uint8_t *src = bytes + gb;
-            for (uint32_t i = 0; i * 64 < nch; i++) {
-                const uint32_t c = i * 64 + (uint32_t)lane;
-                lds_dma16(src + 16ull * (c < nch ? c : nch - 1), lds_base + 1024u * i); // lanes past the span re-read its last piece
+        for (int dd = 32; dd >= 4; dd >>= 1) { uint32_t o = __shfl_xor(e, dd, 64); e = o > e ? o : e; }
+        c.nch = __builtin_amdgcn_readfirstlane((e + 15) >> 4);
+        c.rel = (uint32_t)(off - c.gb);
+        c.kind = sec < c.n ? desc_kind(d) : K_SKIP;
+        return c;
+    };
+
+    uint4 R[REGION_PIECES];
+    auto issue_loads = [&](const ChunkPlan &c) {
+        const uint4 *src = (const uint4 *)(bytes + c.gb);
+        const uint32_t last = c.nch ? c.nch - 1 : 0u; // an empty plan (past the wave's range) re-reads piece 0 of the blob
+#pragma unroll
+        for (int i = 0; i < REGION_PIECES; i++) {
+            const uint32_t k = 64u * i + (uint32_t)lane;
+            R[i] = src[k < c.nch ? k : last]; // unconditional: lanes past the span re-read its last piece
+        }
+    };
+
+#pragma unroll
+    for (int i = 0; i < REGION_PIECES; i++) R[i] = make_uint4(0, 0, 0, 0);
+    if (lane < 16) ((uint32_t *)(data + REGION_SPAN))[lane] = 0;
+    // The first pass of the loop has an empty current chunk: it only plans and loads chunk 0.
+    uint64_t s_cur = sA;
+    ChunkPlan cur;
+    cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP;
+    uint64_t d_next = load_desc(sA);
+    for (;;) {
+        // ---- registers -> staging region ---------------------------------------------------------------------
+        {
+            uint4 *dst = (uint4 *)data;
+#pragma unroll
+            for (int i = 0; i < REGION_PIECES; i++) {
+                const uint32_t k = 64u * i + (uint32_t)lane;
+                if (k < cur.nch) dst[k] = R[i];
             }
         }
-        // descriptors of the next chunk, in flight beside the DMA
-        const uint64_t s_next = s_cur + n;
-        const uint64_t d_next = load_desc(s_next);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // ---- walk + decode ----------------------------------------------------------------------------------------
-        if (sa._pad != 1)
-            process_chunk<ETYPE, MODE, SINGLE>(data, lds_base, sec < n ? desc_kind(d_cur) : K_SKIP, (uint32_t)(off - gb),
-                                               len, sec < n, s_cur + sec, lane, pa, sa, sec_res, masks, out_);
+        // ---- plan the next chunk and start its loads ------------------------------------------------------------
+        // (unconditional, so that the staging registers never become conditionally assigned: past the
+        // wave's range the plan is empty and the loads re-read one piece)
+        const uint64_t s_next = s_cur + cur.n;
+        const ChunkPlan nxt = plan(s_next, d_next);
+        issue_loads(nxt);
+        d_next = load_desc(s_next + nxt.n);
+        // ---- walk + decode the current chunk ----------------------------------------------------------------------
+        if (cur.n != 0 && sa._pad != 1) {
+            const bool odd = process_chunk<ETYPE, MODE, SINGLE, false>(data, lds_base, cur.kind, cur.rel, cur.len,
+                                                                       sec < cur.n, s_cur + sec, lane, pa, sa, sec_res,
+                                                                       masks, out_);
+            if (__ballot(odd) != 0)
+                process_chunk<ETYPE, MODE, SINGLE, true>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
+                                                         s_cur + sec, lane, pa, sa, sec_res, masks, out_);
+        }
+        if (nxt.n == 0) break;
         s_cur = s_next;
-        d_cur = d_next;
+        cur = nxt;
     }
 }
 
