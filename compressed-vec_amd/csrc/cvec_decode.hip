@@ -318,42 +318,61 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
                  : "memory");
 #pragma unroll 4
     for (int k = 0; k < FIXED_LEN / 8; k++) {
-        // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2 ----------------------------
-        const uint32_t hn = nw >> 4; // n - 1
+        // ---- address of the lane's two fields in the current octet; their reads go out first ----------------
+        const uint32_t hn = nw >> 4;        // n - 1
+        const uint32_t n4 = (hn << 2) + 4u; // field width in bits
+        const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
+        const uint32_t A = pa_ + 2u + (b0 >> 3);
+        const uint32_t s = (A << 3) | (b0 & 4u); // funnel shift; only bits 4:0 are used
+        const uint32_t qa = A & ~3u;
+        uint64_t d01;
+        uint32_t d2, d3 = 0, d4 = 0;
+        if constexpr (W == 4) {
+            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
+                         : "=&v"(d01), "=&v"(d2)
+                         : "v"(qa)
+                         : "memory");
+        } else {
+            lds_u32p qd = (lds_u32p)(uintptr_t)qa;
+            d01 = (uint64_t)qd[0] | ((uint64_t)qd[1] << 32);
+            d2 = qd[2]; d3 = qd[3]; d4 = qd[4];
+        }
+        // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2; then the reads of the next
+        //      octet (after the last one: a harmless read of the bytes that follow).  mask and nw pass
+        //      through the statement so that the unpacking below is scheduled behind it. -------------------------
         const uint32_t pc = __popc(mask);
         const uint32_t a3 = (uint32_t)__umul24(min(mask, 1u), 3u) + (pc + 2u);
-        const uint32_t size = ((uint32_t)__umul24(hn, pc) + a3) >> 1;
-        const uint32_t pa_cur = pa_;
-        pa_ += size;
-        // reads of the next octet (after the last one: a harmless read of the bytes that follow);
-        // mask and nw pass through the statement so that the decode below is scheduled behind it
+        pa_ += ((uint32_t)__umul24(hn, pc) + a3) >> 1;
         uint32_t mask_n, nw_n;
         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1"
                      : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
                      : "v"(pa_)
                      : "memory");
-        if constexpr (W == 4 && CAREFUL) hmax = max(hmax, mask ? hn : 0u);
-        // ---- the lane's two fields of the current octet ------------------------------------------------------
-        const uint32_t n4 = (hn << 2) + 4u;       // field width in bits
-        const uint32_t t4 = (nw & 15u) << 2;      // trailing zero bits
-        const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
-        const uint32_t A = pa_cur + 2u + (b0 >> 3);
-        const uint32_t s = (A << 3) | (b0 & 4u);  // funnel shift; only bits 4:0 are used
-        lds_u32p qd = (lds_u32p)(uintptr_t)(A & ~3u);
-        const uint32_t sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
-        const uint32_t sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
+        if constexpr (W == 4 && CAREFUL) hmax = max(hmax, mask ? (nw >> 4) : 0u);
+        // ---- per-octet constants, in the shadow of both reads ----------------------------------------------------
+        uint32_t t4 = (nw & 15u) << 2; // trailing zero bits
+        uint32_t sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
+        uint32_t sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
         if constexpr (W == 4 && !CAREFUL) racc |= nw & (sm0 | sm1); // the quad's lanes cover every stored element
         U x0, x1;
         if constexpr (W == 4) {
-            const uint32_t d0 = qd[0], d1 = qd[1], d2 = qd[2];
-            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s), hi = __builtin_amdgcn_alignbit(d2, d1, s);
             // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
-            const uint32_t fm = (CAREFUL && t4 >= 32u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
-            const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> (n4 & sm0));
-            x0 = ((lo & fm) & sm0) << (t4 & 31u);
-            x1 = ((w1 & fm) & sm1) << (t4 & 31u);
+            uint32_t fm = (CAREFUL && t4 >= 32u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
+            uint32_t sh1 = n4 & sm0;
+            t4 &= 31u;
+            // the field reads have landed once only the two header reads are outstanding (LDS returns in
+            // order); the constants above pass through the statement so that they are computed ahead of it
+            asm volatile("s_waitcnt lgkmcnt(2)"
+                         : "+v"(d01), "+v"(d2), "+v"(fm), "+v"(sh1), "+v"(sm0), "+v"(sm1), "+v"(t4), "+v"(racc)
+                         :
+                         : "memory");
+            const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s), hi = __builtin_amdgcn_alignbit(d2, d1, s);
+            const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh1);
+            x0 = ((lo & fm) & sm0) << t4;
+            x1 = ((w1 & fm) & sm1) << t4;
         } else {
-            const uint32_t d0 = qd[0], d1 = qd[1], d2 = qd[2], d3 = qd[3], d4 = qd[4];
+            const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
             const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, s), w1 = __builtin_amdgcn_alignbit(d2, d1, s),
                            w2 = __builtin_amdgcn_alignbit(d3, d2, s), w3 = __builtin_amdgcn_alignbit(d4, d3, s);
             const uint64_t fm = ~0ull >> ((64u - n4) & 63u);
@@ -399,7 +418,8 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
                 else *(uint4 *)(op + 8 * k) = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mask_n), "+v"(nw_n) : : "memory");
+        // the step's results pass through the wait so that the work above is issued ahead of it
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mask_n), "+v"(nw_n), "+v"(cnt), "+v"(st0), "+v"(st1) : : "memory");
         mask = mask_n;
         nw = nw_n;
     }
