@@ -486,7 +486,9 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         const uint64_t left = s < sB ? sB - s : 0;
         const uint32_t avail = (uint32_t)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
         const uint64_t off = desc_off(d);
-        c.gb = __shfl(off, 0, 64) & ~15ull;
+        const uint64_t off0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(off >> 32)) << 32) |
+                              __builtin_amdgcn_readfirstlane((uint32_t)off);
+        c.gb = off0 & ~15ull;
         uint32_t len = desc_len(d);
         c.len = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
         const uint64_t endl = off + c.len - c.gb; // wraps to a huge value if off < gb
@@ -494,29 +496,28 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         const unsigned long long m = __ballot(fits);
         uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> 2;
         c.n = n < avail ? n : avail;
-        uint32_t e = sec < c.n ? (uint32_t)endl : 0u;
-#pragma unroll
-        for (int dd = 32; dd >= 4; dd >>= 1) { uint32_t o = __shfl_xor(e, dd, 64); e = o > e ? o : e; }
-        c.nch = __builtin_amdgcn_readfirstlane((e + 15) >> 4);
+        // section offsets do not decrease with the slot number, so the span ends with its last section
+        const uint32_t e = c.n ? __builtin_amdgcn_readlane((uint32_t)endl, (int)(4 * (c.n - 1))) : 0u;
+        c.nch = (e + 15) >> 4;
         c.rel = (uint32_t)(off - c.gb);
         c.kind = sec < c.n ? desc_kind(d) : K_SKIP;
         return c;
     };
 
-    uint4 R[REGION_PIECES];
+    // Staging registers: piece i of a span = 64 lanes x 16 bytes.  The loads go through a buffer
+    // descriptor over exactly the span, so lanes past its end cost no traffic and return zeros;
+    // the whole region (zero pad included) is rewritten for every chunk without any per-lane test.
+    typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
+    u32x4 R[REGION_PIECES];
     auto issue_loads = [&](const ChunkPlan &c) {
-        const uint4 *src = (const uint4 *)(bytes + c.gb);
-        const uint32_t last = c.nch ? c.nch - 1 : 0u; // an empty plan (past the wave's range) re-reads piece 0 of the blob
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)(c.nch * 16u), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < REGION_PIECES; i++) {
-            const uint32_t k = 64u * i + (uint32_t)lane;
-            R[i] = src[k < c.nch ? k : last]; // unconditional: lanes past the span re-read its last piece
-        }
+        for (int i = 0; i < REGION_PIECES; i++)
+            R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 0);
     };
 
 #pragma unroll
-    for (int i = 0; i < REGION_PIECES; i++) R[i] = make_uint4(0, 0, 0, 0);
-    if (lane < 16) ((uint32_t *)(data + REGION_SPAN))[lane] = 0;
+    for (int i = 0; i < REGION_PIECES; i++) R[i] = u32x4{0, 0, 0, 0};
     // The first pass of the loop has an empty current chunk: it only plans and loads chunk 0.
     uint64_t s_cur = sA;
     ChunkPlan cur;
@@ -525,16 +526,13 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     for (;;) {
         // ---- registers -> staging region ---------------------------------------------------------------------
         {
-            uint4 *dst = (uint4 *)data;
+            u32x4 *dst = (u32x4 *)data;
 #pragma unroll
-            for (int i = 0; i < REGION_PIECES; i++) {
-                const uint32_t k = 64u * i + (uint32_t)lane;
-                if (k < cur.nch) dst[k] = R[i];
-            }
+            for (int i = 0; i < REGION_PIECES; i++) dst[64 * i + lane] = R[i];
         }
         // ---- plan the next chunk and start its loads ------------------------------------------------------------
         // (unconditional, so that the staging registers never become conditionally assigned: past the
-        // wave's range the plan is empty and the loads re-read one piece)
+        // wave's range the plan is empty and the loads fetch nothing)
         const uint64_t s_next = s_cur + cur.n;
         const ChunkPlan nxt = plan(s_next, d_next);
         issue_loads(nxt);
