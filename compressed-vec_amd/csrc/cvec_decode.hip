@@ -131,9 +131,15 @@ template <int ETYPE>
 __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes,
                                                const uint64_t *__restrict__ byte_off,
                                                const uint64_t *__restrict__ sec_base, uint64_t n,
-                                               uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
-                                               uint64_t *__restrict__ result) {
+                                               uint64_t padded_bytes, uint64_t *__restrict__ desc,
+                                               int32_t *__restrict__ vstatus, uint64_t *__restrict__ result) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
+    // One 4-byte load per section header (type byte + 16-bit length), pulled back inside the padded
+    // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
+    auto load4 = [&](uint64_t a) -> uint32_t {
+        const uint64_t a4 = a + 4 <= padded_bytes ? a : padded_bytes - 4;
+        return *(const u32u *)(bytes + a4) >> (8 * (uint32_t)(a - a4));
+    };
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v < CVEC_RESULT_WORDS) result[v] = 0; // k_finalize accumulates into it two launches later
     if (v >= n) return;
@@ -146,8 +152,10 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     else if (L < 4) st = CVEC_NOT_ENOUGH_SPACE;
     else if (L <= 5) st = CVEC_BAD_OFFSET;
     else {
-        uint64_t from_header = *(const u32u *)p;
-        uint32_t subtype = p[5];
+        const uint64_t a8 = start + 8 <= padded_bytes ? start : padded_bytes - 8; // L >= 6: padded_bytes >= 16
+        const uint64_t h8 = *(const u64u *)(bytes + a8) >> (8 * (uint32_t)(start - a8));
+        uint64_t from_header = (uint32_t)h8;
+        uint32_t subtype = (uint32_t)(h8 >> 40) & 0xffu;
         if (L < from_header + 4) st = CVEC_INPUT_TOO_SHORT;
         else if (subtype != (uint32_t)ETYPE) st = CVEC_WRONG_VECTOR_TYPE;
         else if (L < HEADER_BYTES) st = CVEC_INPUT_TOO_SHORT;
@@ -156,7 +164,8 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     if (st == CVEC_OK) {
         while (pos < L) { // sections are walked to the end of the slice (src/vector.rs:443)
             const uint64_t rem = L - pos;
-            const uint32_t b0 = p[pos];
+            const uint32_t hw = load4(start + pos);
+            const uint32_t b0 = hw & 0xffu;
             uint64_t nb = 0;
             int e = CVEC_OK;
             if (b0 == K_NULL) {
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
                 if (rem <= 1) e = CVEC_BAD_OFFSET;
                 else if (rem < 3) e = CVEC_NOT_ENOUGH_SPACE;
                 else {
-                    uint32_t n16 = *(const u16u *)(p + pos + 1);
+                    uint32_t n16 = (hw >> 8) & 0xffffu;
                     nb = b0 == K_NP ? (uint64_t)n16 + 3 : (b0 == K_DELTA ? (uint64_t)n16 + DELTA_HDR : n16);
                     if (nb > rem) e = CVEC_SCROLL_ERR;
                     else if (nb < 3) e = CVEC_INVALID_FORMAT;
@@ -359,7 +368,6 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
             uint32_t fm = (CAREFUL && t4 >= 32u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
             uint32_t sh1 = n4 & sm0;
-            t4 &= 31u;
             // the field reads have landed once only the two header reads are outstanding (LDS returns in
             // order); the constants above pass through the statement so that they are computed ahead of it
             asm volatile("s_waitcnt lgkmcnt(2)"
@@ -369,8 +377,8 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
             const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s), hi = __builtin_amdgcn_alignbit(d2, d1, s);
             const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh1);
-            x0 = ((lo & fm) & sm0) << t4;
-            x1 = ((w1 & fm) & sm1) << t4;
+            x0 = ((lo & fm) & sm0) << (t4 & 31u);
+            x1 = ((w1 & fm) & sm1) << (t4 & 31u);
         } else {
             const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
             const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, s), w1 = __builtin_amdgcn_alignbit(d2, d1, s),
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)(c.nch * 16u), 0x00020000);
 #pragma unroll
         for (int i = 0; i < REGION_PIECES; i++)
-            R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 0);
+            R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 2 /* nt: read once */);
     };
 
 #pragma unroll
@@ -683,7 +691,8 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
     timer_mark(rec, 0, stream);
     k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
-                                                                                 n, desc, vstatus, d_result);
+                                                                                 n, (b.n_bytes + 15) & ~15ull, desc, vstatus,
+                                                                                 d_result);
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (ns > 0) {
