@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def counter_avg(tag, counter, kernel_substr):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", tag, "*", "*_counter_collection.csv"))
+    files = glob.glob(os.path.join(ROOT, "gpurun_out", tag, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         return None
     vals = collections.defaultdict(float)
@@ -32,7 +32,7 @@ def counter_avg(tag, counter, kernel_substr):
 def main():
     tag = sys.argv[1]
     nvec = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_kt", "*", "*_kernel_stats.csv"))[0]
+    stats = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_kt", "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = [r for r in csv.DictReader(open(stats))]
     out_csv = os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")
     with open(out_csv, "w", newline="") as f:
