@@ -5,12 +5,14 @@
 //   k_index     one lane per vector walks its section headers (the chain of
 //               FixedSectIterator::next, reference src/section.rs:864-876) and writes one
 //               descriptor per 256-element section slot.
-//   k_sections  one workgroup per tile of TILE consecutive section slots: the tile's bytes are one
-//               contiguous span of the blob, staged once into LDS with 16-byte coalesced loads;
-//               one lane per section walks the 32 octet headers (the chain inside
-//               decode_to_sink, src/section.rs:548-553 / :638-641 / :708-711) and leaves a
-//               32-entry octet table in LDS; then every wave decodes whole sections, 4 elements
-//               per lane, undoes XOR with a wavefront scan and either compares (filter) or stores.
+//   k_sections  persistent, wave-autonomous: every wave owns a contiguous range of section slots
+//               and an 18 KiB LDS region, streams 16 sections at a time into it (bounds-checked
+//               16-byte buffer loads -> registers -> LDS, the next chunk prefetched into registers
+//               while the current one is processed) and runs the 32 octet steps of all 16 sections
+//               at once: a quad of lanes per section walks the octet headers (the chain inside
+//               decode_to_sink, src/section.rs:548-553 / :638-641 / :708-711) and each lane pulls
+//               its two elements of every octet straight out of the bitstream, keeps the XOR state
+//               in registers and either compares (filter) or stores.  No barriers, no octet table.
 //   k_finalize  one lane per vector folds its sections' results in order, so a failing section
 //               ends that vector exactly where the reference's iteration would stop.
 #include <stdlib.h>
@@ -138,14 +140,13 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
     auto load4 = [&](uint64_t a) -> uint32_t {
         const uint64_t a4 = a + 4 <= padded_bytes ? a : padded_bytes - 4;
-        return *(const u32u *)(bytes + a4) >> (8 * (uint32_t)(a - a4));
+        return __builtin_nontemporal_load((const u32u *)(bytes + a4)) >> (8 * (uint32_t)(a - a4));
     };
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v < CVEC_RESULT_WORDS) result[v] = 0; // k_finalize accumulates into it two launches later
     if (v >= n) return;
     const uint64_t start = byte_off[v], L = byte_off[v + 1] - start;
     const uint64_t slot0 = sec_base[v], nslots = sec_base[v + 1] - slot0;
-    const uint8_t *p = bytes + start;
     int st = CVEC_OK;
     // scroll pread error mapping of try_new, then the reader's own checks
     if (L == 0) st = CVEC_BAD_OFFSET;
@@ -696,8 +697,6 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (ns > 0) {
-        // Persistent workgroups: two fit a CU (LDS), so 2 x 256 x 2 rounds; each owns a contiguous
-        // range of section slots (a multiple of TILE) and pipelines over it.
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).
         static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 1; }();
@@ -710,7 +709,7 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
         const bool single = pa.count == 1;
         static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
         SinkArgs sa2 = sa;
-        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage only, 3 = compute only
+        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage the bytes but skip the octet loop
 #define CVEC_LAUNCH_SEC(M, S)                                                                                       \
     k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
         if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);

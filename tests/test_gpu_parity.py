@@ -301,6 +301,37 @@ def test_malformed_vectors_report_status_and_partial_counts(cv, oracle):
     assert list(dst) == list(wst)
 
 
+def test_overwide_shift_octets_take_the_exact_path(cv, oracle):
+    """Hand-made 32-bit sections whose octets carry 8 or more trailing zero nibbles (an encoder never
+    writes them: the lanes shift out to 0, src/nibblepack_simd.rs:581) must decode like the oracle;
+    the kernel's common path only detects them and a second exact pass handles them."""
+    def section(kind, octets):
+        body = b"".join(octets) + b"\x00" * (32 - len(octets))
+        if kind == 1:                               # NibblePack: length excludes the 3-byte header
+            return bytes([1]) + len(body).to_bytes(2, "little") + body
+        return bytes([6]) + (len(body) + 3).to_bytes(2, "little") + body   # Xor: length includes it
+    octs = [bytes([0b00000101, 0x19, 0xab, 0xcd]),   # n = 2, t = 9: both stored lanes shift out
+            bytes([0xff, 0x07] + [0x21, 0x43, 0x65, 0x87]),   # n = 1, t = 7: ordinary
+            bytes([0b10000001, 0x3c, 0x34, 0x12, 0x78, 0x56])]  # n = 4, t = 12
+    for tname, kind in (("u32", 1), ("f32", 6)):
+        sect = section(kind, octs)
+        body = sect + sect                         # two sections: 512 elements
+        hdr = (len(body) + 12).to_bytes(4, "little") + bytes([0x10, ET[tname]]) + b"\x00\x00" + \
+            (512).to_bytes(4, "little") + b"\x00\x00\x00\x00"
+        vec = hdr + body
+        want = oracle.decode_to_vec(ET[tname], vec)
+        plain = oracle.encode_all(ET[tname], np.arange(700).astype(NPD[tname]))
+        host = cv.EncodedBatch.from_vectors(tname, [plain, vec, plain])
+        dev = host.to_device()
+        dec, off, st = dev.decode(return_status=True)
+        assert list(st) == [0, 0, 0]
+        assert np.array_equal(_bits(dec[int(off[1]):int(off[1]) + 512]), _bits(want))
+        for pred in (0, want[8] if want[8] != 0 else 1):
+            total, per, st = dev.filter_count(pred, per_vector=True, return_status=True)
+            wtotal, wper, wst, _ = oracle.batch_filter_count(ET[tname], host.blob, host.byte_off, pred)
+            assert list(st) == list(wst) and np.array_equal(per, wper) and total == wtotal
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
