@@ -25,30 +25,48 @@ template <int ETYPE> struct EncT {
     using U = typename Elem<W>::U;
 };
 
+// Cross-lane moves as DPP (register-to-register, no LDS round trip): CTRL is the DPP control word,
+// ROW_MASK selects the 16-lane rows that are written (the others keep `old`), BOUND zero-fills lanes
+// whose source lies outside the row.
+template <int CTRL, int ROW_MASK, bool BOUND> __device__ inline uint32_t dpp_mov(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, BOUND);
+}
+template <int CTRL, int ROW_MASK, bool BOUND> __device__ inline uint64_t dpp_mov(uint64_t old, uint64_t v) {
+    return (uint64_t)dpp_mov<CTRL, ROW_MASK, BOUND>((uint32_t)old, (uint32_t)v) |
+           ((uint64_t)dpp_mov<CTRL, ROW_MASK, BOUND>((uint32_t)(old >> 32), (uint32_t)(v >> 32)) << 32);
+}
+template <int CTRL, int ROW_MASK, bool BOUND> __device__ inline float dpp_mov(float old, float v) {
+    return __uint_as_float(dpp_mov<CTRL, ROW_MASK, BOUND>(__float_as_uint(old), __float_as_uint(v)));
+}
+constexpr int DPP_QUAD_1032 = 0xb1, DPP_QUAD_2301 = 0x4e, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ inline uint32_t lane63(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+__device__ inline uint64_t lane63(uint64_t x) { return (uint64_t)lane63((uint32_t)x) | ((uint64_t)lane63((uint32_t)(x >> 32)) << 32); }
+__device__ inline float lane63(float x) { return __uint_as_float(lane63(__float_as_uint(x))); }
+
+// Wave-wide reduction with an idempotent-safe combine (min / max / or: combining a lane with itself
+// is harmless, which the masked row broadcasts rely on); the result is uniform (read from lane 63).
+template <class T, class Op> __device__ inline T wave_reduce(T x, Op op) {
+    x = op(x, dpp_mov<DPP_QUAD_1032, 0xf, false>(x, x));
+    x = op(x, dpp_mov<DPP_QUAD_2301, 0xf, false>(x, x));
+    x = op(x, dpp_mov<DPP_ROW_HALF_MIRROR, 0xf, false>(x, x));
+    x = op(x, dpp_mov<DPP_ROW_MIRROR, 0xf, false>(x, x));        // every lane: its row's result
+    x = op(x, dpp_mov<DPP_ROW_BCAST15, 0xa, false>(x, x));       // rows 1, 3 <- rows 0, 2
+    x = op(x, dpp_mov<DPP_ROW_BCAST31, 0xc, false>(x, x));       // rows 2, 3 <- rows 0..1
+    return lane63(x);
+}
 template <class U> __device__ inline U wave_min_u(U x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { U y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
-    return x;
+    return wave_reduce<U>(x, [](U a, U b) { return b < a ? b : a; });
 }
 template <class U> __device__ inline U wave_max_u(U x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { U y = __shfl_xor(x, d, 64); x = y > x ? y : x; }
-    return x;
+    return wave_reduce<U>(x, [](U a, U b) { return b > a ? b : a; });
 }
 __device__ inline float wave_min_f(float x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { float y = __shfl_xor(x, d, 64); x = y < x ? y : x; }
-    return x;
+    return wave_reduce<float>(x, [](float a, float b) { return b < a ? b : a; });
 }
 __device__ inline float wave_max_f(float x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { float y = __shfl_xor(x, d, 64); x = y > x ? y : x; }
-    return x;
-}
-__device__ inline uint32_t wave_sum_u32(uint32_t x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    return x;
+    return wave_reduce<float>(x, [](float a, float b) { return b > a ? b : a; });
 }
 __device__ inline uint32_t bitlen_u(uint32_t x) { return x ? 32u - (uint32_t)__clz(x) : 0u; }
 __device__ inline uint32_t bitlen_u(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }
@@ -119,12 +137,13 @@ __device__ inline void transform_section(typename EncT<ETYPE>::U x[4], uint32_t 
                                          typename EncT<ETYPE>::U minv, int lane) {
     using U = typename EncT<ETYPE>::U;
     if constexpr (ETYPE == CVEC_F32) {
+        // element e-8 sits 8 lanes below in the same register, or (lanes 0..7) in lanes 56..63 of the
+        // previous register: one lane rotation by 8 of a register that already holds the wrap values
         U prev[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            U up = __shfl_up(x[i], 8, 64);                                   // element e-8, lanes >= 8
-            U wrap = i > 0 ? __shfl(x[i > 0 ? i - 1 : 0], (lane + 56) & 63, 64) : (U)0; // lanes < 8
-            prev[i] = lane >= 8 ? up : wrap;
+            const U src = lane >= 56 ? (i > 0 ? x[i > 0 ? i - 1 : 0] : (U)0) : x[i];
+            prev[i] = __shfl(src, (lane + 56) & 63, 64);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] ^= prev[i];
@@ -134,6 +153,19 @@ __device__ inline void transform_section(typename EncT<ETYPE>::U x[4], uint32_t 
             for (int i = 0; i < 4; i++) x[i] -= minv;
         }
     }
+}
+
+// Inclusive scan over the 8 octet groups of a wave (group g = lanes 8g..8g+7, all lanes of a group
+// holding the same value) and its total: stride 8 inside a 16-lane row, then row broadcasts.
+struct GroupScan { uint32_t incl, total; };
+__device__ inline GroupScan group_scan_total(uint32_t v) {
+    GroupScan r;
+    uint32_t x = v + dpp_mov<DPP_ROW_SHR8, 0xf, true>(0u, v);
+    x += dpp_mov<DPP_ROW_BCAST15, 0xa, false>(0u, x);
+    x += dpp_mov<DPP_ROW_BCAST31, 0xc, false>(0u, x);
+    r.incl = x;
+    r.total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    return r;
 }
 
 struct OctInfo {
@@ -147,9 +179,9 @@ template <class U> __device__ inline OctInfo octet_info(U y, int lane) {
     const unsigned long long b = __ballot(y != 0);
     o.mask = (uint32_t)(b >> (lane & 56)) & 0xffu;
     U r = y;
-    r |= __shfl_xor(r, 1, 64);
-    r |= __shfl_xor(r, 2, 64);
-    r |= __shfl_xor(r, 4, 64);
+    r |= dpp_mov<DPP_QUAD_1032, 0xf, false>(r, r);
+    r |= dpp_mov<DPP_QUAD_2301, 0xf, false>(r, r);
+    r |= dpp_mov<DPP_ROW_HALF_MIRROR, 0xf, false>(r, r);
     if (o.mask) {
         uint32_t lz, tz;
         if constexpr (sizeof(U) == 8) { lz = (uint32_t)__clzll((long long)r); tz = (uint32_t)__ffsll((long long)r) - 1; }
@@ -214,11 +246,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const typename EncT<E
         transform_section<ETYPE>(x, p.kind, p.minv, lane);
         uint32_t s = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const OctInfo o = octet_info<U>(x[i], lane);
-            s += (lane & 7) == 0 ? o.size : 0;
-        }
-        size = (p.kind == K_DELTA ? DELTA_HDR : 3) + wave_sum_u32(s);
+        for (int i = 0; i < 4; i++) s += octet_info<U>(x[i], lane).size; // every lane of a group holds its octet's size
+        size = (p.kind == K_DELTA ? DELTA_HDR : 3) + group_scan_total(s).total;
     }
     if (lane == 0) sec_size[slot] = size;
 }
@@ -250,7 +279,9 @@ __global__ void k_enc_headers(int32_t etype, const uint64_t *__restrict__ elem_o
 }
 
 // ---- pass B: emit ---------------------------------------------------------------------------------------
-template <int W> struct EncBuf { static constexpr int DWORDS = (SectLimits<W>::MAX_BYTES + 3) / 4 + 3; };
+// LDS image of one section, built at the same 16-byte phase as its destination so that the copy-out
+// is aligned 16-byte traffic on both sides (a misaligned LDS read costs ~16x an aligned one on gfx950).
+template <int W> struct EncBuf { static constexpr int DWORDS = ((SectLimits<W>::MAX_BYTES + 15 + 15) / 16 + 1) * 4; };
 
 template <int ETYPE>
 __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ETYPE>::U *__restrict__ values,
@@ -261,7 +292,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
                                                            uint8_t *__restrict__ bytes) {
     using U = typename EncT<ETYPE>::U;
     constexpr int W = EncT<ETYPE>::W;
-    __shared__ uint32_t s_buf[ENC_THREADS / 64][EncBuf<W>::DWORDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[ENC_THREADS / 64][EncBuf<W>::DWORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t slot = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + wave;
     if (slot >= max_slots) return;
@@ -289,9 +320,10 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
         return;
     }
     uint32_t *buf = s_buf[wave];
-    uint8_t *bufb = (uint8_t *)buf;
-    const uint32_t ndw = (size + 3) / 4 + 1;
-    for (uint32_t d = lane; d < ndw; d += 64) buf[d] = 0;
+    const uint32_t phase = (uint32_t)(dst_off & 15);   // bytes is 16-byte aligned: the phase of dst itself
+    uint8_t *bufb = (uint8_t *)buf + phase;            // section byte 0
+    const uint32_t npieces = (phase + size + 15) >> 4; // 16-byte pieces of the image
+    for (uint32_t d = lane; d < npieces; d += 64) ((uint4 *)buf)[d] = make_uint4(0, 0, 0, 0);
     const uint32_t hdr = p.kind == K_DELTA ? DELTA_HDR : 3;
     if (lane == 0) {
         bufb[0] = (uint8_t)p.kind;
@@ -305,25 +337,22 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
         }
     }
     transform_section<ETYPE>(x, p.kind, p.minv, lane);
-    const uint32_t g = lane >> 3, j = lane & 7;
+    const uint32_t j = lane & 7;
     uint32_t carry = hdr;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const OctInfo o = octet_info<U>(x[i], lane);
         // exclusive scan of the octet sizes of groups 0..7 of this register
-        uint32_t incl = o.size;
-        uint32_t y = __shfl_up(incl, 8, 64);  if (g >= 1) incl += y;
-        y = __shfl_up(incl, 16, 64);          if (g >= 2) incl += y;
-        y = __shfl_up(incl, 32, 64);          if (g >= 4) incl += y;
-        const uint32_t off = carry + incl - o.size;
-        carry += __shfl(incl, 63, 64);
+        const GroupScan gs = group_scan_total(o.size);
+        const uint32_t off = carry + gs.incl - o.size;
+        carry += gs.total;
         if (j == 0) {
             bufb[off] = (uint8_t)o.mask;
             if (o.mask) bufb[off + 1] = (uint8_t)(((o.n - 1) << 4) | o.t);
         }
         if (x[i] != 0) {
             const uint32_t idx = __popc(o.mask & ((1u << j) - 1u));
-            const uint32_t bitpos = (off + 2) * 8 + idx * 4 * o.n;
+            const uint32_t bitpos = (phase + off + 2) * 8 + idx * 4 * o.n;
             const U field = x[i] >> (4 * o.t);
             const uint32_t d = bitpos >> 5, sh = bitpos & 31;
             if constexpr (W == 4) {
@@ -342,15 +371,18 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
     // byte stores above and the atomic ORs are LDS operations of ONE wave: they complete in order,
     // so the image is final here without a barrier.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // copy out: unaligned head bytes, aligned dwords, tail bytes
-    const uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3)) & 3);
-    const uint32_t h = head < size ? head : size;
-    if ((uint32_t)lane < h) dst[lane] = bufb[lane];
-    const uint32_t nd = (size - h) >> 2;
-    uint32_t *dst4 = (uint32_t *)(dst + h);
-    for (uint32_t d = lane; d < nd; d += 64) dst4[d] = *(const u32u *)(bufb + h + 4 * d);
-    const uint32_t tail0 = h + 4 * nd;
-    if (tail0 + lane < size) dst[tail0 + lane] = bufb[tail0 + lane];
+    // copy out: whole 16-byte pieces as aligned dwordx4, the partial first / last piece byte by byte
+    const uint8_t *img = (const uint8_t *)buf;
+    uint8_t *gdst = dst - phase; // 16-byte aligned
+    for (uint32_t d = lane; d < npieces; d += 64) {
+        const uint32_t lo = 16 * d, hi = lo + 16;
+        if (lo >= phase && hi <= phase + size) {
+            *(uint4 *)(gdst + lo) = ((const uint4 *)buf)[d];
+        } else {
+            const uint32_t b0 = lo > phase ? lo : phase, b1 = hi < phase + size ? hi : phase + size;
+            for (uint32_t b = b0; b < b1; b++) gdst[b] = img[b];
+        }
+    }
 }
 
 // ---- launcher --------------------------------------------------------------------------------------------

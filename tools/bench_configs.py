@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Side measurements on batches shaped like the reference's `cargo bench vector` configurations
+(benches/bench.rs:131-170): encode_all, decode through AddConst -> VecSink, and filter + count, each
+in GB/s of uncompressed bytes, with the values generated on the device.  Not the headline benchmark
+(bench.py); prints one JSON object per configuration."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import compressed_vec_amd as cv  # noqa: E402
+from compressed_vec_amd import synth  # noqa: E402
+
+
+def timed(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def run(name, tname, kind, nvec, length, pred, add_const):
+    chunks = []
+    for c0 in range(0, nvec, 4096):
+        chunks.append(synth.batch_values_torch(kind, min(4096, nvec - c0), length, v_first=c0)[0])
+    vals = torch.cat(chunks)
+    eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * length
+    raw = vals.numel() * vals.element_size()
+    batch = cv.encode_device(tname, vals, eo)
+    t_enc = timed(lambda: cv.encode_device(tname, vals, eo), 5)
+    out = torch.empty(batch.n_sections * 256, dtype=vals.dtype, device="cuda")
+    t_dec = timed(lambda: batch.decode_async(out, add_const=add_const))
+    res = batch.result_buffer()
+    p = cv.make_pred(batch.etype, pred)
+    t_fil = timed(lambda: batch.filter_count_async(p, result=res))
+    got = int(res[0].item())
+    want = int((vals == pred).sum().item())
+    if kind != "f32_xor":                       # padding matches a zero predicate only
+        assert got == want, (got, want)
+    print(json.dumps({"config": name, "vectors": nvec, "vector_len": length, "raw_MiB": raw >> 20,
+                      "compressed_B_per_elem": round(batch.n_bytes / vals.numel(), 3),
+                      "encode_GBs": round(raw / t_enc / 1e9, 1), "decode_GBs": round(raw / t_dec / 1e9, 1),
+                      "filter_GBs": round(raw / t_fil / 1e9, 1), "filter_matches": got}), flush=True)
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 26214          # x 10000 x 4 B = 1 GiB
+    run("cfg1 u32 dense", "u32", "u32_dense", n, 10000, 3, 7)
+    run("cfg3 f32 xor", "f32", "f32_xor", n, 10000, 3.0, 2.5)
+    run("cfg4 u64 delta", "u64", "u64_delta", n // 2, 10000, 100003, 5)
