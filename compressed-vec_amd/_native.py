@@ -51,6 +51,13 @@ class DBatchView(C.Structure):
                 ("d_sec_base", C.c_void_p)]
 
 
+class MaskColumn(C.Structure):
+    _fields_ = [("d_masks", C.c_void_p), ("d_sec_base", C.c_void_p), ("d_valid", C.c_void_p),
+                ("n_sections", C.c_uint64)]
+
+
+MAX_COLUMNS = 16
+
 # Every symbol include/cvec.h declares, with its signature.
 SIGNATURES = {
     "cvec_version": (C.c_char_p, []),
@@ -67,6 +74,14 @@ SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_decode_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(SinkChain), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_valid_sections_dev": (C.c_int32, [C.POINTER(DBatchView), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "cvec_multi_workspace_bytes": (C.c_size_t, [C.c_uint64]),
+    "cvec_multi_filter_count_dev": (C.c_int32, [C.POINTER(MaskColumn), C.c_uint32, C.c_uint64, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_void_p]),
+    "cvec_positions_workspace_bytes": (C.c_size_t, [C.c_uint64]),
+    "cvec_match_positions_dev": (C.c_int32, [C.POINTER(MaskColumn), C.c_uint64, C.c_void_p, C.c_void_p,
+                                             C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_max_encoded_bytes": (C.c_size_t, [C.c_int32, C.c_uint64, C.c_uint64]),
     "cvec_encode_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
     "cvec_encode_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,

@@ -200,6 +200,18 @@ class DeviceBatch:
             out.append(mk.cpu().numpy())
         return out[0] if len(out) == 1 else tuple(out)
 
+    def filter_masks(self, pred):
+        """Runs the filter pass and keeps its per-section masks on the device: returns a FilteredColumn
+        (masks, number of sections every vector yielded) for multi_filter_count / match_positions."""
+        masks = torch.zeros(self.n_sections * 32, dtype=torch.uint8, device=self.device)
+        res = self.filter_count_async(pred, masks=masks)
+        valid = torch.empty(max(self.n_vectors, 1), dtype=torch.int32, device=self.device)
+        ws = self.workspace()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().cvec_valid_sections_dev(C.byref(self.view), _ptr(ws), ws.numel(), _ptr(valid),
+                                                    _stream_ptr()))
+        return FilteredColumn(self, masks, valid, res.clone())
+
     def decode_async(self, out, add_const=None, status=None, result=None):
         """Enqueues decode through [AddConstSink →] VecSink into `out` (256 * n_sections elements)."""
         assert out.numel() >= self.n_sections * FIXED_LEN and out.element_size() == WIDTH[self.etype]
@@ -221,6 +233,62 @@ class DeviceBatch:
         vals = out.cpu().numpy().view(NP_DTYPE[self.etype])
         off = self.d_sec_base.cpu().numpy().view(np.uint64) * np.uint64(FIXED_LEN)
         return (vals, off, st.cpu().numpy()) if return_status else (vals, off)
+
+
+class FilteredColumn:
+    """The masks of one filter pass over a DeviceBatch (what the reference's VectorFilter yields, for
+    every vector of the batch), resident on the device."""
+
+    def __init__(self, batch, masks, valid, result):
+        self.batch, self.masks, self.valid, self.result = batch, masks, valid, result
+        c = N.MaskColumn()
+        c.d_masks, c.d_sec_base, c.d_valid = masks.data_ptr(), batch.d_sec_base.data_ptr(), valid.data_ptr()
+        c.n_sections = batch.n_sections
+        self.column = c
+
+    def match_positions(self):
+        """filter::match_positions for every vector: (positions uint32, pos_off uint64[n+1])."""
+        b = self.batch
+        lib = N.lib()
+        ws = torch.empty(lib.cvec_positions_workspace_bytes(b.n_sections), dtype=torch.uint8, device=b.device)
+        pos_off = torch.empty(b.n_vectors + 1, dtype=torch.int64, device=b.device)
+        cap = b.n_sections * FIXED_LEN
+        pos = torch.empty(max(cap, 1), dtype=torch.int32, device=b.device)
+        with torch.cuda.device(b.device):
+            N.check(lib.cvec_match_positions_dev(C.byref(self.column), b.n_vectors, _ptr(pos_off), _ptr(pos), cap,
+                                                 _ptr(ws), ws.numel(), _stream_ptr()))
+        off = pos_off.cpu().numpy().view(np.uint64)
+        return pos[:int(off[-1])].cpu().numpy().view(np.uint32), off
+
+
+def multi_filter_count(columns, per_row=False, return_masks=False):
+    """MultiVectorFilter + count_hits (reference src/filter.rs:239-299) over FilteredColumns with the same
+    number of vectors: row r ANDs the masks of vector r of every column.  Returns the total
+    (and per-row counts / (ANDed masks, masks yielded per row) on request)."""
+    k = len(columns)
+    if not 1 <= k <= N.MAX_COLUMNS:
+        raise N.CodingError(N.ERR_BAD_ARGUMENT, "1..%d columns" % N.MAX_COLUMNS)
+    b0 = columns[0].batch
+    n = b0.n_vectors
+    if any(c.batch.n_vectors != n for c in columns):
+        raise N.CodingError(N.ERR_BAD_ARGUMENT, "columns differ in the number of vectors")
+    arr = (N.MaskColumn * k)(*[c.column for c in columns])
+    lib = N.lib()
+    ws = torch.empty(lib.cvec_multi_workspace_bytes(b0.n_sections), dtype=torch.uint8, device=b0.device)
+    res = torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device=b0.device)
+    pr = torch.empty(n, dtype=torch.int64, device=b0.device) if per_row else None
+    rs = torch.empty(max(n, 1), dtype=torch.int32, device=b0.device) if return_masks else None
+    mk = torch.zeros(b0.n_sections * 32, dtype=torch.uint8, device=b0.device) if return_masks else None
+    with torch.cuda.device(b0.device):
+        N.check(lib.cvec_multi_filter_count_dev(arr, k, n, _ptr(res), _ptr(pr), _ptr(rs), _ptr(mk), _ptr(ws),
+                                                ws.numel(), _stream_ptr()))
+    out = [int(res[0].item())]
+    if per_row:
+        out.append(pr.cpu().numpy().view(np.uint64))
+    if return_masks:
+        out.append(mk.cpu().numpy())
+        out.append(rs.cpu().numpy()[:n])
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def encode_device(etype, d_values, d_elem_off, n_elements_total=None):

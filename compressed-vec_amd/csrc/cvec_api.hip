@@ -16,6 +16,21 @@ hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, 
                        int32_t *d_status, uint8_t *d_masks, void *d_out, hipStream_t stream);
 hipError_t timing_begin(int max_records);
 hipError_t timing_end(float ms[3], int *n_records);
+// cvec_filter_ops.hip
+struct MaskColumns {
+    const uint8_t *masks[CVEC_MAX_PRED_VALUES];
+    const uint64_t *sec_base[CVEC_MAX_PRED_VALUES];
+    const uint32_t *valid[CVEC_MAX_PRED_VALUES];
+    uint32_t k;
+};
+hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uint64_t *desc, const uint32_t *sec_res,
+                                 const int32_t *vstatus, uint32_t *valid, hipStream_t stream);
+hipError_t launch_multi_and(const MaskColumns &cols, uint64_t n_rows, uint64_t n_slots0, uint8_t *out_masks,
+                            uint16_t *popc, uint8_t *ended, uint64_t *per_row, uint32_t *row_sections,
+                            uint64_t *result, hipStream_t stream);
+hipError_t launch_match_positions(const uint8_t *masks, const uint64_t *sec_base, uint64_t n, const uint32_t *valid,
+                                  uint64_t n_slots, uint64_t *counts, uint64_t *scan, uint64_t *scan_scratch,
+                                  uint64_t *pos_off, uint32_t *positions, uint64_t cap, hipStream_t stream);
 // cvec_encode.hip
 size_t encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
 hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
@@ -233,6 +248,75 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
     hipError_t e = launch_read(1, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status, nullptr,
                                d_out, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_decode_dev");
+    return CVEC_OK;
+}
+
+static_assert(CVEC_MAX_COLUMNS == CVEC_MAX_PRED_VALUES, "MaskColumns is sized by CVEC_MAX_PRED_VALUES");
+
+cvec_status cvec_valid_sections_dev(const cvec_dbatch_view *batch, const void *d_workspace, size_t workspace_bytes,
+                                    uint32_t *d_valid, void *stream) {
+    cvec_status st = check_view(batch);
+    if (st) return st;
+    if (!d_workspace || (batch->n_vectors && !d_valid)) return CVEC_ERR_BAD_ARGUMENT;
+    ReadWs w = carve_read_ws((void *)d_workspace, batch->n_vectors, batch->n_sections);
+    if (w.total > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    hipError_t e = launch_valid_sections(batch->d_sec_base, batch->n_vectors, w.desc, w.sec_res, w.vstatus, d_valid,
+                                         (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_valid_sections_dev");
+    return CVEC_OK;
+}
+
+// multi workspace: popc[n] u16 | ended[n] u8
+size_t cvec_multi_workspace_bytes(uint64_t n_sections_col0) {
+    return align_up((n_sections_col0 + 1) * 2, 256) + align_up(n_sections_col0 + 1, 256);
+}
+
+cvec_status cvec_multi_filter_count_dev(const cvec_mask_column *cols, uint32_t k, uint64_t n_rows,
+                                        uint64_t *d_result, uint64_t *d_per_row, uint32_t *d_row_sections,
+                                        uint8_t *d_masks_out, void *d_workspace, size_t workspace_bytes,
+                                        void *stream) {
+    if (!cols || k == 0 || k > CVEC_MAX_COLUMNS || !d_result || !d_workspace) return CVEC_ERR_BAD_ARGUMENT;
+    MaskColumns mc;
+    memset(&mc, 0, sizeof(mc));
+    mc.k = k;
+    for (uint32_t c = 0; c < k; c++) {
+        if (!cols[c].d_sec_base || (n_rows && !cols[c].d_valid) || (cols[c].n_sections && !cols[c].d_masks))
+            return CVEC_ERR_BAD_ARGUMENT;
+        if (((uintptr_t)cols[c].d_masks & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
+        mc.masks[c] = cols[c].d_masks; mc.sec_base[c] = cols[c].d_sec_base; mc.valid[c] = cols[c].d_valid;
+    }
+    if (((uintptr_t)d_masks_out & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
+    const uint64_t n0 = cols[0].n_sections;
+    if (cvec_multi_workspace_bytes(n0) > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    uint16_t *popc = (uint16_t *)d_workspace;
+    uint8_t *ended = (uint8_t *)d_workspace + align_up((n0 + 1) * 2, 256);
+    hipError_t e = launch_multi_and(mc, n_rows, n0, d_masks_out, popc, ended, d_per_row, d_row_sections, d_result,
+                                    (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_multi_filter_count_dev");
+    return CVEC_OK;
+}
+
+// positions workspace: counts[n] u64 | scan[n+1] u64 | scan scratch
+size_t cvec_positions_workspace_bytes(uint64_t n_sections) {
+    return align_up((n_sections + 1) * 8, 256) * 2 + align_up(scan_scratch_words(n_sections) * 8, 256);
+}
+
+cvec_status cvec_match_positions_dev(const cvec_mask_column *col, uint64_t n_vectors, uint64_t *d_pos_off,
+                                     uint32_t *d_positions, uint64_t positions_cap, void *d_workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!col || !col->d_sec_base || !d_pos_off || !d_workspace) return CVEC_ERR_BAD_ARGUMENT;
+    if ((n_vectors && !col->d_valid) || (col->n_sections && !col->d_masks) || (positions_cap && !d_positions))
+        return CVEC_ERR_BAD_ARGUMENT;
+    if (((uintptr_t)col->d_masks & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
+    const uint64_t ns = col->n_sections;
+    if (cvec_positions_workspace_bytes(ns) > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    uint8_t *b = (uint8_t *)d_workspace;
+    uint64_t *counts = (uint64_t *)b;
+    uint64_t *scan = (uint64_t *)(b + align_up((ns + 1) * 8, 256));
+    uint64_t *scratch = (uint64_t *)(b + 2 * align_up((ns + 1) * 8, 256));
+    hipError_t e = launch_match_positions(col->d_masks, col->d_sec_base, n_vectors, col->d_valid, ns, counts, scan,
+                                          scratch, d_pos_off, d_positions, positions_cap, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_match_positions_dev");
     return CVEC_OK;
 }
 

@@ -1,0 +1,186 @@
+// cvec_filter_ops.hip — gfx950 kernels that consume the per-section 256-bit masks of the filter pass:
+// MultiVectorFilter (reference src/filter.rs:239-286: AND of the masks of several vectors, section
+// by section) and match_positions (src/filter.rs:302-321: element positions of the set bits).
+// Both are plain streaming kernels over 32-byte masks; the decode work was done by k_sections.
+#include "cvec_device.hpp"
+
+namespace cvec {
+
+hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_scratch,
+                                 hipStream_t stream);
+uint64_t scan_scratch_words(uint64_t n);
+
+// Row (vector index) of a global section slot: the last v with sec_base[v] <= slot.
+__device__ inline uint64_t row_of_slot(const uint64_t *__restrict__ sec_base, uint64_t n, uint64_t slot) {
+    uint64_t lo = 0, hi = n; // invariant: sec_base[lo] <= slot < sec_base[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sec_base[mid] <= slot) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Number of leading sections of every vector that yield a mask / decoded data: the reference's
+// iteration stops at the first section that fails (src/filter.rs:226) or cannot be parsed.
+__global__ __launch_bounds__(256) void k_valid_sections(const uint64_t *__restrict__ sec_base, uint64_t n,
+                                                        const uint64_t *__restrict__ desc,
+                                                        const uint32_t *__restrict__ sec_res,
+                                                        const int32_t *__restrict__ vstatus,
+                                                        uint32_t *__restrict__ valid) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t a = sec_base[v], b = sec_base[v + 1];
+    uint64_t s = a;
+    for (; s < b; s++)
+        if (desc_kind(desc[s]) == K_SKIP || (sec_res[s] >> 16) != 0) break;
+    valid[v] = (uint32_t)(s - a);
+}
+
+struct MaskColumns {
+    const uint8_t *masks[CVEC_MAX_PRED_VALUES];
+    const uint64_t *sec_base[CVEC_MAX_PRED_VALUES];
+    const uint32_t *valid[CVEC_MAX_PRED_VALUES];
+    uint32_t k;
+};
+
+// One thread per section slot of column 0: AND the masks of the other columns in order, consulting
+// column c only while the running mask is non-zero (the short-circuit of src/filter.rs:269-282).
+// `ended` records that a consulted column had no section left, which ends the row's iteration.
+__global__ __launch_bounds__(256) void k_multi_and(MaskColumns cols, uint64_t n_rows, uint64_t n_slots0,
+                                                   uint8_t *__restrict__ out_masks, uint16_t *__restrict__ popc,
+                                                   uint8_t *__restrict__ ended) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots0) return;
+    const uint64_t r = row_of_slot(cols.sec_base[0], n_rows, slot);
+    const uint64_t s = slot - cols.sec_base[0][r];
+    uint4 m0 = make_uint4(0, 0, 0, 0), m1 = m0;
+    bool end = s >= cols.valid[0][r];
+    if (!end) {
+        const uint4 *p = (const uint4 *)(cols.masks[0] + 32 * slot);
+        m0 = p[0]; m1 = p[1];
+        for (uint32_t c = 1; c < cols.k; c++) {
+            if ((m0.x | m0.y | m0.z | m0.w | m1.x | m1.y | m1.z | m1.w) == 0) break;
+            if (s >= cols.valid[c][r]) { end = true; break; }
+            const uint4 *q = (const uint4 *)(cols.masks[c] + 32 * (cols.sec_base[c][r] + s));
+            const uint4 a = q[0], b = q[1];
+            m0.x &= a.x; m0.y &= a.y; m0.z &= a.z; m0.w &= a.w;
+            m1.x &= b.x; m1.y &= b.y; m1.z &= b.z; m1.w &= b.w;
+        }
+    }
+    popc[slot] = (uint16_t)(__popc(m0.x) + __popc(m0.y) + __popc(m0.z) + __popc(m0.w) + __popc(m1.x) + __popc(m1.y) +
+                            __popc(m1.z) + __popc(m1.w));
+    ended[slot] = end ? 1 : 0;
+    if (out_masks) {
+        uint4 *o = (uint4 *)(out_masks + 32 * slot);
+        o[0] = m0; o[1] = m1;
+    }
+}
+
+// One thread per row: sections up to the first ended one count (src/filter.rs:262-273).
+__global__ __launch_bounds__(256) void k_multi_rows(const uint64_t *__restrict__ sec_base0, uint64_t n_rows,
+                                                    const uint16_t *__restrict__ popc,
+                                                    const uint8_t *__restrict__ ended,
+                                                    uint64_t *__restrict__ per_row, uint32_t *__restrict__ row_sections,
+                                                    uint64_t *__restrict__ result) {
+    __shared__ uint64_t s_cnt[4];
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t cnt = 0;
+    if (r < n_rows) {
+        const uint64_t a = sec_base0[r], b = sec_base0[r + 1];
+        uint64_t s = a;
+        for (; s < b && !ended[s]; s++) cnt += popc[s];
+        if (per_row) per_row[r] = cnt;
+        if (row_sections) row_sections[r] = (uint32_t)(s - a);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)&result[0], s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]);
+}
+
+// ---- match_positions ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mask_counts(const uint8_t *__restrict__ masks,
+                                                     const uint64_t *__restrict__ sec_base, uint64_t n,
+                                                     const uint32_t *__restrict__ valid, uint64_t n_slots,
+                                                     uint64_t *__restrict__ counts) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const uint64_t r = row_of_slot(sec_base, n, slot);
+    uint32_t c = 0;
+    if (slot - sec_base[r] < valid[r]) {
+        const uint4 *p = (const uint4 *)(masks + 32 * slot);
+        const uint4 a = p[0], b = p[1];
+        c = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+    }
+    counts[slot] = c;
+}
+
+// Eight threads per section, one per 32-bit mask word: positions are written in increasing order
+// (true positions: the reference's loop forgets to advance over all-zero words, src/filter.rs:309).
+__global__ __launch_bounds__(256) void k_mask_positions(const uint8_t *__restrict__ masks,
+                                                        const uint64_t *__restrict__ sec_base, uint64_t n,
+                                                        const uint32_t *__restrict__ valid, uint64_t n_slots,
+                                                        const uint64_t *__restrict__ scan, uint32_t *__restrict__ positions,
+                                                        uint64_t cap) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t slot = t >> 3;
+    const uint32_t w = (uint32_t)t & 7;
+    if (slot >= n_slots) return;
+    const uint64_t r = row_of_slot(sec_base, n, slot);
+    const uint64_t s = slot - sec_base[r];
+    if (s >= valid[r]) return;
+    const uint32_t *m = (const uint32_t *)(masks + 32 * slot);
+    uint64_t o = scan[slot]; // offset of this section's first position in the batch-wide list
+    for (uint32_t i = 0; i < w; i++) o += __popc(m[i]);
+    uint32_t bits = m[w];
+    const uint32_t base = (uint32_t)(256 * s + 32 * w);
+    while (bits) {
+        const uint32_t b = __ffs((int)bits) - 1;
+        if (o < cap) positions[o] = base + b;
+        o++;
+        bits &= bits - 1;
+    }
+}
+
+__global__ void k_pos_off(const uint64_t *__restrict__ sec_base, uint64_t n, const uint64_t *__restrict__ scan,
+                          uint64_t *__restrict__ pos_off) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v <= n) pos_off[v] = scan[sec_base[v]];
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------
+hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uint64_t *desc, const uint32_t *sec_res,
+                                 const int32_t *vstatus, uint32_t *valid, hipStream_t stream) {
+    if (n) k_valid_sections<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(sec_base, n, desc, sec_res, vstatus, valid);
+    return hipGetLastError();
+}
+
+hipError_t launch_multi_and(const MaskColumns &cols, uint64_t n_rows, uint64_t n_slots0, uint8_t *out_masks,
+                            uint16_t *popc, uint8_t *ended, uint64_t *per_row, uint32_t *row_sections,
+                            uint64_t *result, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return e;
+    if (n_slots0)
+        k_multi_and<<<(uint32_t)((n_slots0 + 255) / 256), 256, 0, stream>>>(cols, n_rows, n_slots0, out_masks, popc, ended);
+    if (n_rows)
+        k_multi_rows<<<(uint32_t)((n_rows + 255) / 256), 256, 0, stream>>>(cols.sec_base[0], n_rows, popc, ended, per_row,
+                                                                          row_sections, result);
+    return hipGetLastError();
+}
+
+hipError_t launch_match_positions(const uint8_t *masks, const uint64_t *sec_base, uint64_t n, const uint32_t *valid,
+                                  uint64_t n_slots, uint64_t *counts, uint64_t *scan, uint64_t *scan_scratch,
+                                  uint64_t *pos_off, uint32_t *positions, uint64_t cap, hipStream_t stream) {
+    if (n_slots)
+        k_mask_counts<<<(uint32_t)((n_slots + 255) / 256), 256, 0, stream>>>(masks, sec_base, n, valid, n_slots, counts);
+    hipError_t e = launch_exclusive_scan(counts, n_slots, scan, scan_scratch, stream);
+    if (e != hipSuccess) return e;
+    if (n_slots)
+        k_mask_positions<<<(uint32_t)((8 * n_slots + 255) / 256), 256, 0, stream>>>(masks, sec_base, n, valid, n_slots, scan,
+                                                                                  positions, cap);
+    k_pos_off<<<(uint32_t)((n + 256) / 256), 256, 0, stream>>>(sec_base, n, scan, pos_off);
+    return hipGetLastError();
+}
+
+} // namespace cvec

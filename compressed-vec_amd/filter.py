@@ -66,9 +66,37 @@ class VectorFilter:
         return self._count
 
 
+class MultiVectorFilter:
+    """MultiVectorFilter::new(vec![filters]) (src/filter.rs:239-286): iterating it yields the AND of the
+    filters' masks section by section; ends with the first filter, or with a later one that is
+    consulted (running mask non-zero) and has no section left."""
+
+    def __init__(self, vect_filters):
+        if not vect_filters:
+            raise ValueError("Cannot pass in empty filters to MultiVectorFilter")  # panics in the reference
+        self._filters = list(vect_filters)
+        self._masks = None
+
+    def _run(self):
+        if self._masks is None:
+            from .batch import multi_filter_count
+            cols = [f._reader._device_batch().filter_masks(f._sink.pred) for f in self._filters]
+            total, masks, row_sections = multi_filter_count(cols, return_masks=True)
+            self._count = total
+            self._masks = masks.reshape(-1, 32)[:int(row_sections[0])]
+
+    def __iter__(self):
+        self._run()
+        return iter(self._masks)
+
+    def count_hits(self):
+        self._run()
+        return self._count
+
+
 def count_hits(filter_iter):
     """filter::count_hits (src/filter.rs:296-299)."""
-    if isinstance(filter_iter, VectorFilter):
+    if isinstance(filter_iter, (VectorFilter, MultiVectorFilter)):
         return filter_iter.count_hits()
     return int(sum(int(np.unpackbits(np.asarray(m, dtype=np.uint8)).sum()) for m in filter_iter))
 

@@ -141,6 +141,46 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
                             uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
                             void *stream);
 
+/* ---- consumers of the per-section masks ----------------------------------------------------- */
+
+/* The number of leading sections of every vector that the last cvec_filter_count_dev /
+ * cvec_decode_dev on `batch` with this workspace produced: the reference's section iteration ends
+ * at the first section that fails to decode (src/filter.rs:226) or to parse.  d_valid: n_vectors
+ * u32.  Masks / decoded data of later sections are unspecified. */
+cvec_status cvec_valid_sections_dev(const cvec_dbatch_view *batch, const void *d_workspace, size_t workspace_bytes,
+                                    uint32_t *d_valid, void *stream);
+
+/* One filtered vector column: the masks cvec_filter_count_dev wrote for a batch, that batch's
+ * sec_base and the valid-section counts from cvec_valid_sections_dev. */
+#define CVEC_MAX_COLUMNS 16
+typedef struct cvec_mask_column {
+    const uint8_t *d_masks;      /* n_sections * 32 bytes */
+    const uint64_t *d_sec_base;  /* n_vectors + 1 */
+    const uint32_t *d_valid;     /* n_vectors */
+    uint64_t n_sections;
+} cvec_mask_column;
+
+/* MultiVectorFilter + count_hits (src/filter.rs:239-286, :296-299) for n_rows rows of k columns:
+ * row r ANDs the masks of vector r of every column section by section, consulting column c only
+ * while the running mask is non-zero, and ends where column 0 or a consulted column has no section
+ * left.  d_result[0] = total; d_per_row (nullable) n_rows u64; d_row_sections (nullable) n_rows u32
+ * = masks yielded per row; d_masks_out (nullable) the ANDed masks in column 0's slot layout. */
+size_t cvec_multi_workspace_bytes(uint64_t n_sections_col0);
+cvec_status cvec_multi_filter_count_dev(const cvec_mask_column *cols, uint32_t k, uint64_t n_rows,
+                                        uint64_t *d_result, uint64_t *d_per_row, uint32_t *d_row_sections,
+                                        uint8_t *d_masks_out, void *d_workspace, size_t workspace_bytes,
+                                        void *stream);
+
+/* filter::match_positions (src/filter.rs:302-321) for every vector of a column: the element
+ * positions (relative to the vector) of the set mask bits, ascending, vectors back to back:
+ * vector v's positions are d_positions[d_pos_off[v] .. d_pos_off[v+1]).  Unlike the reference's
+ * loop these are true positions (its `pos` is not advanced over all-zero 32-bit mask words).
+ * Positions beyond positions_cap are dropped; d_pos_off[n_vectors] is the number needed. */
+size_t cvec_positions_workspace_bytes(uint64_t n_sections);
+cvec_status cvec_match_positions_dev(const cvec_mask_column *col, uint64_t n_vectors, uint64_t *d_pos_off,
+                                     uint32_t *d_positions, uint64_t positions_cap, void *d_workspace,
+                                     size_t workspace_bytes, void *stream);
+
 /* Vector{U32,U64,F32Xor}Appender::encode_all for n_vectors vectors: vector v's elements are
  * d_values[elem_off[v] .. elem_off[v+1]).  Replaces src/vector.rs:238-246 (append → encode_section
  * → finish) with AutoEncoder (src/section.rs:819-846) for u32/u64 and XorNPMedFixedSect

@@ -332,6 +332,47 @@ def test_overwide_shift_octets_take_the_exact_path(cv, oracle):
             assert list(st) == list(wst) and np.array_equal(per, wper) and total == wtotal
 
 
+def test_multi_vector_filter_and_positions_vs_oracle(cv, oracle):
+    """MultiVectorFilter + count_hits (src/filter.rs:239-299) and match_positions over device-resident masks."""
+    rng = np.random.default_rng(77)
+    n = 60
+    lens = rng.integers(1, 1500, size=n)
+    cols_vals, blobs = [], []
+    for c in range(3):
+        vecs = []
+        for v in range(n):
+            ln = int(lens[v]) if c < 2 else max(1, int(lens[v]) - 300 * (v % 5 == 0))   # column 2: some shorter vectors
+            x = rng.integers(0, 4, size=ln).astype(np.uint32)
+            if v % 7 == c:
+                x[:] = 0                                                             # Null sections: short-circuit rows
+            vecs.append(oracle.encode_all(oracle.U32, x))
+        blobs.append(vecs)
+    preds = [1, 2, 1]
+    devs = [cv.EncodedBatch.from_vectors("u32", b).to_device() for b in blobs]
+    cols = [d.filter_masks(p) for d, p in zip(devs, preds)]
+    total, per_row, masks, row_sections = cv.multi_filter_count(cols, per_row=True, return_masks=True)
+    sb0 = devs[0].d_sec_base.cpu().numpy()
+    want_total = 0
+    for v in range(n):
+        cnt, wm = oracle.multi_filter_count(oracle.U32, [blobs[c][v] for c in range(3)], preds, return_masks=True)
+        want_total += cnt
+        assert per_row[v] == cnt, v
+        ns = wm.size // 32
+        assert row_sections[v] == ns, v
+        assert np.array_equal(masks[32 * int(sb0[v]):32 * (int(sb0[v]) + ns)], wm), v
+    assert total == want_total
+    # the API mirror: two filters over one vector each
+    r0, r1 = cv.VectorReader.try_new(blobs[0][3], "u32"), cv.VectorReader.try_new(blobs[1][3], "u32")
+    mf = cv.MultiVectorFilter([r0.filter_iter(cv.EqualsSink("u32", 1)), r1.filter_iter(cv.EqualsSink("u32", 2))])
+    assert cv.count_hits(mf) == oracle.multi_filter_count(oracle.U32, [blobs[0][3], blobs[1][3]], [1, 2])
+    # match_positions of a single column, every vector
+    pos, off = cols[0].match_positions()
+    for v in range(n):
+        _, wm = oracle.filter_count(oracle.U32, blobs[0][v], preds[0], return_masks=True)
+        want = oracle.match_positions(wm)
+        assert np.array_equal(pos[int(off[v]):int(off[v + 1])].astype(np.uint64), want), v
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
