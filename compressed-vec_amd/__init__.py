@@ -5,6 +5,7 @@ from ._native import (CodingError, F32, U32, U64, LIB_PATH, lib)
 from .batch import (DeviceBatch, EncodedBatch, FilteredColumn, encode_batch, encode_device, etype_of, make_pred,
                     multi_filter_count)
 from .filter import EqualsSink, MultiVectorFilter, OneOfSink, VectorFilter, count_hits, match_positions
+from . import stream
 from .sink import AddConstSink, Section256Sink, VecSink
 from .vector import (VectorAppender, VectorF32XorAppender, VectorReader, VectorU32Appender, VectorU64Appender)
 

@@ -57,6 +57,7 @@ class MaskColumn(C.Structure):
 
 
 MAX_COLUMNS = 16
+STREAM_U64_DELTA, STREAM_F64_XOR = 1, 2
 
 # Every symbol include/cvec.h declares, with its signature.
 SIGNATURES = {
@@ -82,6 +83,15 @@ SIGNATURES = {
     "cvec_positions_workspace_bytes": (C.c_size_t, [C.c_uint64]),
     "cvec_match_positions_dev": (C.c_int32, [C.POINTER(MaskColumn), C.c_uint64, C.c_void_p, C.c_void_p,
                                              C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_stream_max_packed_bytes": (C.c_size_t, [C.c_int32, C.c_uint64, C.c_uint64]),
+    "cvec_stream_pack_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
+    "cvec_stream_pack_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "cvec_stream_unpack_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
+    "cvec_stream_unpack_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                           C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]),
     "cvec_max_encoded_bytes": (C.c_size_t, [C.c_int32, C.c_uint64, C.c_uint64]),
     "cvec_encode_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
     "cvec_encode_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,

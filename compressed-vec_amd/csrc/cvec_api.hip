@@ -31,6 +31,15 @@ hipError_t launch_multi_and(const MaskColumns &cols, uint64_t n_rows, uint64_t n
 hipError_t launch_match_positions(const uint8_t *masks, const uint64_t *sec_base, uint64_t n, const uint32_t *valid,
                                   uint64_t n_slots, uint64_t *counts, uint64_t *scan, uint64_t *scan_scratch,
                                   uint64_t *pos_off, uint32_t *positions, uint64_t cap, hipStream_t stream);
+// cvec_stream.hip / cvec_encode.hip: legacy stream codecs
+size_t stream_unpack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total);
+hipError_t launch_stream_unpack(int kind, const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                const uint64_t *d_elem_off, uint64_t n, uint64_t n_values_total, uint64_t *d_out,
+                                int32_t *d_status, uint64_t *d_result, void *d_ws, hipStream_t stream);
+size_t stream_pack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total);
+hipError_t launch_stream_pack(int kind, const uint64_t *d_values, const uint64_t *d_elem_off, uint64_t n,
+                              uint64_t n_values_total, uint8_t *d_bytes, uint64_t *d_byte_off, int32_t *d_status,
+                              uint64_t *d_result, void *d_ws, hipStream_t stream);
 // cvec_encode.hip
 size_t encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
 hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
@@ -317,6 +326,50 @@ cvec_status cvec_match_positions_dev(const cvec_mask_column *col, uint64_t n_vec
     hipError_t e = launch_match_positions(col->d_masks, col->d_sec_base, n_vectors, col->d_valid, ns, counts, scan,
                                           scratch, d_pos_off, d_positions, positions_cap, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_match_positions_dev");
+    return CVEC_OK;
+}
+
+static inline bool stream_kind_ok(int32_t k) { return k == CVEC_STREAM_U64_DELTA || k == CVEC_STREAM_F64_XOR; }
+
+size_t cvec_stream_max_packed_bytes(int32_t kind, uint64_t n_streams, uint64_t n_values_total) {
+    // every octet at most 2 + 64 bytes; a stream of n values has ceil(n/8) octets; XOR streams add 8 raw bytes
+    (void)kind;
+    return (size_t)((n_values_total / 8 + n_streams) * 66 + n_streams * 8 + 64);
+}
+size_t cvec_stream_pack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total) {
+    return stream_pack_workspace_bytes(n_streams, n_values_total);
+}
+cvec_status cvec_stream_pack_dev(int32_t kind, const uint64_t *d_values, const uint64_t *d_elem_off,
+                                 uint64_t n_streams, uint64_t n_values_total, uint8_t *d_bytes, size_t bytes_cap,
+                                 uint64_t *d_byte_off, int32_t *d_status, uint64_t *d_result, void *d_workspace,
+                                 size_t workspace_bytes, void *stream) {
+    if (!stream_kind_ok(kind) || !d_elem_off || !d_bytes || !d_byte_off || !d_result || !d_workspace)
+        return CVEC_ERR_BAD_ARGUMENT;
+    if (n_values_total && !d_values) return CVEC_ERR_BAD_ARGUMENT;
+    if (((uintptr_t)d_bytes & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
+    if (bytes_cap < cvec_stream_max_packed_bytes(kind, n_streams, n_values_total)) return CVEC_NOT_ENOUGH_SPACE;
+    if (stream_pack_workspace_bytes(n_streams, n_values_total) > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    hipError_t e = launch_stream_pack(kind, d_values, d_elem_off, n_streams, n_values_total, d_bytes, d_byte_off,
+                                      d_status, d_result, d_workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_stream_pack_dev");
+    return CVEC_OK;
+}
+
+size_t cvec_stream_unpack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total) {
+    return stream_unpack_workspace_bytes(n_streams, n_values_total);
+}
+cvec_status cvec_stream_unpack_dev(int32_t kind, const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                   const uint64_t *d_elem_off, uint64_t n_streams, uint64_t n_values_total,
+                                   uint64_t *d_out, int32_t *d_status, uint64_t *d_result, void *d_workspace,
+                                   size_t workspace_bytes, void *stream) {
+    if (!stream_kind_ok(kind) || !d_byte_off || !d_elem_off || !d_status || !d_result || !d_workspace)
+        return CVEC_ERR_BAD_ARGUMENT;
+    if ((n_bytes && !d_bytes) || (n_values_total && !d_out)) return CVEC_ERR_BAD_ARGUMENT;
+    if (((uintptr_t)d_bytes & 15) != 0 || n_bytes >= (1ull << 40)) return CVEC_ERR_BAD_ARGUMENT;
+    if (stream_unpack_workspace_bytes(n_streams, n_values_total) > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    hipError_t e = launch_stream_unpack(kind, d_bytes, d_byte_off, n_bytes, d_elem_off, n_streams, n_values_total, d_out,
+                                        d_status, d_result, d_workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_stream_unpack_dev");
     return CVEC_OK;
 }
 

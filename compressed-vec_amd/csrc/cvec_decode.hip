@@ -16,6 +16,7 @@
 //   k_finalize  one lane per vector folds its sections' results in order, so a failing section
 //               ends that vector exactly where the reference's iteration would stop.
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -259,9 +260,10 @@ __device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CV
 // elements, src/nibblepacking.rs:474-500 for 64-bit): empty input, length < 3, n > 8, payload too
 // long.  Rare path (malformed input only); plain byte reads.
 template <int W>
-__device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, uint32_t end) {
+__device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, uint32_t end, bool raw) {
     for (int k = 0; k < FIXED_LEN / 8; k++) {
         const int rem = (int)end - (int)p;
+        if (rem == 0 && raw) return 0; // a stream's last block may hold fewer than 32 octets
         if (rem <= 0) return CVEC_NOT_ENOUGH_SPACE;
         const uint32_t mask = data[p];
         if (mask == 0) { p += 1; continue; }
@@ -303,11 +305,11 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
     const uint32_t q = lane & 3;
-    const bool isoct = live && (kind == K_NP || kind == K_DELTA || kind == K_XOR);
+    const bool isoct = live && (kind == K_NP || kind == K_DELTA || kind == K_XOR || kind == K_RAW);
     const bool isconst = live && kind == K_CONST, isdelta = live && kind == K_DELTA;
     const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
     const uint32_t end = rel + len;
-    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : 3u) : REGION_SPAN;
+    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : (kind == K_RAW ? 0u : 3u)) : REGION_SPAN;
     // Const value (section byte 1) or Delta base (section byte 4)
     U v = 0;
     if (isconst || isdelta) v = lds_load_unaligned<W>(lds_base + rel + (isconst ? 1u : 4u));
@@ -436,7 +438,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     uint32_t status = 0;
     if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
     const uint32_t p_end = pa_ - lds_base;
-    if (isoct && (p_end > end || (W == 4 && CAREFUL && hmax > 7))) status = walk_status<W>(data, p0, end);
+    if (isoct && (p_end > end || (W == 4 && CAREFUL && hmax > 7))) status = walk_status<W>(data, p0, end, kind == K_RAW);
     uint32_t count;
     if constexpr (MODE == MODE_DECODE) {
         count = FIXED_LEN;
@@ -683,19 +685,10 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
     return hipGetLastError();
 }
 
+// Launches k_sections over a descriptor table (one descriptor per 256-element slot).
 template <int ETYPE>
-static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
-                          uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
-                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
-                          hipStream_t stream) {
-    const uint64_t n = b.n_vectors, ns = b.n_sections;
-    const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
-    timer_mark(rec, 0, stream);
-    k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
-                                                                                 n, (b.n_bytes + 15) & ~15ull, desc, vstatus,
-                                                                                 d_result);
-    timer_mark(rec, 1, stream);
-    timer_mark(rec, 2, stream);
+static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
+                            const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).
@@ -711,12 +704,40 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
         SinkArgs sa2 = sa;
         sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage the bytes but skip the octet loop
 #define CVEC_LAUNCH_SEC(M, S)                                                                                       \
-    k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(b.d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
+    k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
         if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);
         else if (d_masks) { if (single) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, true); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, false); }
         else { if (single) CVEC_LAUNCH_SEC(MODE_FILTER, true); else CVEC_LAUNCH_SEC(MODE_FILTER, false); }
 #undef CVEC_LAUNCH_SEC
     }
+}
+
+// Decodes a table of bare 64-bit octet blocks (K_RAW descriptors built by the legacy stream index)
+// into out[256 * slot ...]; sec_res receives one status word per block.
+hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, uint64_t n_blocks, uint32_t *sec_res,
+                                 uint64_t *d_out, hipStream_t stream) {
+    PredArgs pa;
+    SinkArgs sa;
+    memset(&pa, 0, sizeof(pa));
+    memset(&sa, 0, sizeof(sa));
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, stream);
+    return hipGetLastError();
+}
+
+template <int ETYPE>
+static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
+                          uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
+                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
+                          hipStream_t stream) {
+    const uint64_t n = b.n_vectors, ns = b.n_sections;
+    const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
+    timer_mark(rec, 0, stream);
+    k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
+                                                                                 n, (b.n_bytes + 15) & ~15ull, desc, vstatus,
+                                                                                 d_result);
+    timer_mark(rec, 1, stream);
+    timer_mark(rec, 2, stream);
+    launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, stream);
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
     if (n > 0)

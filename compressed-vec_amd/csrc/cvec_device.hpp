@@ -15,6 +15,7 @@ constexpr int DELTA_HDR = 12;    // Delta section header (reference src/section.
 // Section kinds as stored in a section descriptor: the reference's type bytes
 // (src/section.rs:32-38) plus two internal markers.
 constexpr uint32_t K_NULL = 0, K_NP = 1, K_DELTA = 3, K_CONST = 5, K_XOR = 6;
+constexpr uint32_t K_RAW = 2;        // internal: up to 32 bare octets of a legacy NibblePack stream, no section header
 constexpr uint32_t K_ILLEGAL = 0x7e; // well-formed section of a kind the element type cannot hold
 constexpr uint32_t K_SKIP = 0x7f;    // slot after a parse error / beyond the sections found
 

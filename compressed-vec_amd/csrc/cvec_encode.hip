@@ -278,9 +278,74 @@ __global__ void k_enc_headers(int32_t etype, const uint64_t *__restrict__ elem_o
     h[14] = 0; h[15] = 0;
 }
 
+// ---- LDS image of a run of octets -----------------------------------------------------------------
+// The image of a section (or of a block of a legacy stream) is built in LDS at the same 16-byte
+// phase as its destination, so that the copy-out is aligned 16-byte traffic on both sides (a
+// misaligned LDS read costs ~16x an aligned one on gfx950).
+
+// Octets 8i+g (register i, lane group g) with index < noct: header bytes by the group's first lane,
+// every nonzero lane ORs its field into the zeroed image.  `first` = byte offset of octet 0 in the
+// section; `phase` = position of section byte 0 in the image.
+template <class U>
+__device__ inline void image_octets(const U x[4], int lane, uint32_t *buf, uint32_t phase, uint32_t first,
+                                    uint32_t noct) {
+    constexpr int W = sizeof(U);
+    uint8_t *bufb = (uint8_t *)buf + phase;
+    const uint32_t g = lane >> 3, j = lane & 7;
+    uint32_t carry = first;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const OctInfo o = octet_info<U>(x[i], lane);
+        const bool exists = 8u * i + g < noct;
+        const uint32_t osize = exists ? o.size : 0u;
+        // exclusive scan of the octet sizes of groups 0..7 of this register
+        const GroupScan gs = group_scan_total(osize);
+        const uint32_t off = carry + gs.incl - osize;
+        carry += gs.total;
+        if (j == 0 && exists) {
+            bufb[off] = (uint8_t)o.mask;
+            if (o.mask) bufb[off + 1] = (uint8_t)(((o.n - 1) << 4) | o.t);
+        }
+        if (x[i] != 0 && exists) {
+            const uint32_t idx = __popc(o.mask & ((1u << j) - 1u));
+            const uint32_t bitpos = (phase + off + 2) * 8 + idx * 4 * o.n;
+            const U field = x[i] >> (4 * o.t);
+            const uint32_t d = bitpos >> 5, sh = bitpos & 31;
+            if constexpr (W == 4) {
+                const uint64_t w = (uint64_t)field << sh;
+                atomicOr(&buf[d], (uint32_t)w);
+                if ((uint32_t)(w >> 32)) atomicOr(&buf[d + 1], (uint32_t)(w >> 32));
+            } else {
+                const uint64_t lo = field << sh;
+                const uint32_t hi = sh ? (uint32_t)(field >> (64 - sh)) : 0u;
+                atomicOr(&buf[d], (uint32_t)lo);
+                if ((uint32_t)(lo >> 32)) atomicOr(&buf[d + 1], (uint32_t)(lo >> 32));
+                if (hi) atomicOr(&buf[d + 2], hi);
+            }
+        }
+    }
+    // byte stores above and the atomic ORs are LDS operations of ONE wave: they complete in order,
+    // so the image is final here without a barrier.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+// Whole 16-byte pieces as aligned dwordx4, the partial first / last piece byte by byte.
+__device__ inline void image_copy_out(const uint32_t *buf, uint32_t phase, uint32_t size, uint8_t *dst, int lane) {
+    const uint8_t *img = (const uint8_t *)buf;
+    uint8_t *gdst = dst - phase; // 16-byte aligned
+    const uint32_t npieces = (phase + size + 15) >> 4;
+    for (uint32_t d = lane; d < npieces; d += 64) {
+        const uint32_t lo = 16 * d, hi = lo + 16;
+        if (lo >= phase && hi <= phase + size) {
+            *(uint4 *)(gdst + lo) = ((const uint4 *)buf)[d];
+        } else {
+            const uint32_t b0 = lo > phase ? lo : phase, b1 = hi < phase + size ? hi : phase + size;
+            for (uint32_t b = b0; b < b1; b++) gdst[b] = img[b];
+        }
+    }
+}
+
 // ---- pass B: emit ---------------------------------------------------------------------------------------
-// LDS image of one section, built at the same 16-byte phase as its destination so that the copy-out
-// is aligned 16-byte traffic on both sides (a misaligned LDS read costs ~16x an aligned one on gfx950).
 template <int W> struct EncBuf { static constexpr int DWORDS = ((SectLimits<W>::MAX_BYTES + 15 + 15) / 16 + 1) * 4; };
 
 template <int ETYPE>
@@ -337,52 +402,190 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
         }
     }
     transform_section<ETYPE>(x, p.kind, p.minv, lane);
-    const uint32_t j = lane & 7;
-    uint32_t carry = hdr;
+    image_octets<U>(x, lane, buf, phase, hdr, 32);
+    image_copy_out(buf, phase, size, dst, lane);
+}
+
+// ---- legacy stream codecs: pack_u64_delta / pack_f64_xor (reference src/nibblepacking.rs:15-45) ----
+// A stream is cut into blocks of 32 octets (256 packed values), one wave per block, exactly like a
+// section without header.  Packed value i of a stream: delta codec = v[i] - v[i-1], clipped at 0
+// (saturating_sub, :18), v[-1] = 0; XOR codec = bits(v[i+1]) ^ bits(v[i]) (the first value is
+// stored raw in front, :31-44).  pack_u64 zero-pads the last octet (:85-91).
+template <int KIND>
+__device__ inline void load_stream_block(const uint64_t *__restrict__ v, uint64_t npacked, uint64_t i0, int lane,
+                                         uint64_t x[4]) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const OctInfo o = octet_info<U>(x[i], lane);
-        // exclusive scan of the octet sizes of groups 0..7 of this register
-        const GroupScan gs = group_scan_total(o.size);
-        const uint32_t off = carry + gs.incl - o.size;
-        carry += gs.total;
-        if (j == 0) {
-            bufb[off] = (uint8_t)o.mask;
-            if (o.mask) bufb[off + 1] = (uint8_t)(((o.n - 1) << 4) | o.t);
-        }
-        if (x[i] != 0) {
-            const uint32_t idx = __popc(o.mask & ((1u << j) - 1u));
-            const uint32_t bitpos = (phase + off + 2) * 8 + idx * 4 * o.n;
-            const U field = x[i] >> (4 * o.t);
-            const uint32_t d = bitpos >> 5, sh = bitpos & 31;
-            if constexpr (W == 4) {
-                const uint64_t w = (uint64_t)field << sh;
-                atomicOr(&buf[d], (uint32_t)w);
-                if ((uint32_t)(w >> 32)) atomicOr(&buf[d + 1], (uint32_t)(w >> 32));
+        const uint64_t idx = i0 + 64 * i + lane;
+        uint64_t y = 0;
+        if (idx < npacked) {
+            if (KIND == CVEC_STREAM_F64_XOR) {
+                y = v[idx + 1] ^ v[idx];
             } else {
-                const uint64_t lo = field << sh;
-                const uint32_t hi = sh ? (uint32_t)(field >> (64 - sh)) : 0u;
-                atomicOr(&buf[d], (uint32_t)lo);
-                if ((uint32_t)(lo >> 32)) atomicOr(&buf[d + 1], (uint32_t)(lo >> 32));
-                if (hi) atomicOr(&buf[d + 2], hi);
+                const uint64_t cur = v[idx], prev = idx ? v[idx - 1] : 0;
+                y = cur >= prev ? cur - prev : 0;
             }
         }
+        x[i] = y;
     }
-    // byte stores above and the atomic ORs are LDS operations of ONE wave: they complete in order,
-    // so the image is final here without a barrier.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // copy out: whole 16-byte pieces as aligned dwordx4, the partial first / last piece byte by byte
-    const uint8_t *img = (const uint8_t *)buf;
-    uint8_t *gdst = dst - phase; // 16-byte aligned
-    for (uint32_t d = lane; d < npieces; d += 64) {
-        const uint32_t lo = 16 * d, hi = lo + 16;
-        if (lo >= phase && hi <= phase + size) {
-            *(uint4 *)(gdst + lo) = ((const uint4 *)buf)[d];
-        } else {
-            const uint32_t b0 = lo > phase ? lo : phase, b1 = hi < phase + size ? hi : phase + size;
-            for (uint32_t b = b0; b < b1; b++) gdst[b] = img[b];
-        }
+}
+
+__device__ inline uint64_t stream_of_block(const uint64_t *__restrict__ blk_base, uint64_t n, uint64_t blk) {
+    uint64_t lo = 0, hi = n; // last s with blk_base[s] <= blk
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (blk_base[mid] <= blk) lo = mid; else hi = mid;
     }
+    return lo;
+}
+
+__device__ inline uint64_t stream_packed_values(int kind, uint64_t n) {
+    return kind == CVEC_STREAM_F64_XOR ? (n ? n - 1 : 0) : n;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ENC_THREADS) void k_stream_sizes(const uint64_t *__restrict__ values,
+                                                               const uint64_t *__restrict__ elem_off,
+                                                               const uint64_t *__restrict__ blk_base, uint64_t n,
+                                                               uint64_t max_blocks, uint64_t *__restrict__ blk_size) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t blk = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + (threadIdx.x >> 6);
+    if (blk >= max_blocks) return;
+    if (blk >= blk_base[n]) { if (lane == 0) blk_size[blk] = 0; return; }
+    const uint64_t s = stream_of_block(blk_base, n, blk);
+    const uint64_t npacked = stream_packed_values(KIND, elem_off[s + 1] - elem_off[s]);
+    const uint64_t i0 = (blk - blk_base[s]) * FIXED_LEN;
+    const uint32_t noct = (uint32_t)(((npacked - i0 < FIXED_LEN ? npacked - i0 : FIXED_LEN) + 7) / 8);
+    uint64_t x[4];
+    load_stream_block<KIND>(values + elem_off[s], npacked, i0, lane, x);
+    uint32_t sz = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t o = octet_info<uint64_t>(x[i], lane).size;
+        sz += 8u * i + (lane >> 3) < noct ? o : 0u;
+    }
+    const uint32_t total = group_scan_total(sz).total;
+    if (lane == 0) blk_size[blk] = total;
+}
+
+__global__ void k_stream_ext(int kind, const uint64_t *__restrict__ elem_off, uint64_t n, uint64_t *__restrict__ ext) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    ext[s] = (kind == CVEC_STREAM_F64_XOR && elem_off[s + 1] > elem_off[s]) ? 8 : 0; // the raw first value
+}
+
+__global__ void k_stream_offsets(int kind, const uint64_t *__restrict__ values, const uint64_t *__restrict__ elem_off,
+                                 const uint64_t *__restrict__ blk_base, const uint64_t *__restrict__ blk_scan,
+                                 const uint64_t *__restrict__ ext_scan, uint64_t n, uint8_t *__restrict__ bytes,
+                                 uint64_t *__restrict__ byte_off, int32_t *__restrict__ status,
+                                 uint64_t *__restrict__ result) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n) return;
+    const uint64_t start = blk_scan[blk_base[s]] + ext_scan[s];
+    byte_off[s] = start;
+    if (s == n) { result[0] = start; return; }
+    int st = CVEC_OK;
+    if (kind == CVEC_STREAM_F64_XOR) {
+        if (elem_off[s + 1] == elem_off[s]) st = CVEC_INPUT_TOO_SHORT; // pack_f64_xor needs one value (:37)
+        else *(u64u *)(bytes + start) = values[elem_off[s]];
+    }
+    if (status) status[s] = st;
+    if (st) { atomicAdd((unsigned long long *)&result[1], 1ull); atomicMax((unsigned long long *)&result[2], (unsigned long long)st); }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ENC_THREADS) void k_stream_emit(const uint64_t *__restrict__ values,
+                                                              const uint64_t *__restrict__ elem_off,
+                                                              const uint64_t *__restrict__ blk_base, uint64_t n,
+                                                              uint64_t max_blocks, const uint64_t *__restrict__ blk_scan,
+                                                              const uint64_t *__restrict__ byte_off,
+                                                              uint8_t *__restrict__ bytes) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[ENC_THREADS / 64][EncBuf<8>::DWORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t blk = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + wave;
+    if (blk >= max_blocks || blk >= blk_base[n]) return;
+    const uint64_t s = stream_of_block(blk_base, n, blk);
+    const uint64_t npacked = stream_packed_values(KIND, elem_off[s + 1] - elem_off[s]);
+    const uint64_t i0 = (blk - blk_base[s]) * FIXED_LEN;
+    const uint32_t noct = (uint32_t)(((npacked - i0 < FIXED_LEN ? npacked - i0 : FIXED_LEN) + 7) / 8);
+    const uint32_t size = (uint32_t)(blk_scan[blk + 1] - blk_scan[blk]);
+    const uint64_t dst_off = byte_off[s] + (KIND == CVEC_STREAM_F64_XOR ? 8 : 0) + (blk_scan[blk] - blk_scan[blk_base[s]]);
+    uint64_t x[4];
+    load_stream_block<KIND>(values + elem_off[s], npacked, i0, lane, x);
+    uint32_t *buf = s_buf[wave];
+    const uint32_t phase = (uint32_t)(dst_off & 15);
+    const uint32_t npieces = (phase + size + 15) >> 4;
+    for (uint32_t d = lane; d < npieces; d += 64) ((uint4 *)buf)[d] = make_uint4(0, 0, 0, 0);
+    image_octets<uint64_t>(x, lane, buf, phase, 0, noct);
+    image_copy_out(buf, phase, size, bytes + dst_off, lane);
+}
+
+struct StreamPackWs {
+    uint64_t *nblk, *blk_base, *ext, *ext_scan, *scan_scratch, *blk_size, *blk_scan, *scan_scratch2;
+    size_t total;
+};
+static StreamPackWs carve_stream_pack(void *base, uint64_t n, uint64_t max_blocks) {
+    StreamPackWs w;
+    uint8_t *b = (uint8_t *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { uint8_t *p = b + off; off += (bytes + 255) / 256 * 256; return p; };
+    w.nblk = (uint64_t *)take((n + 1) * 8);
+    w.blk_base = (uint64_t *)take((n + 1) * 8);
+    w.ext = (uint64_t *)take((n + 1) * 8);
+    w.ext_scan = (uint64_t *)take((n + 1) * 8);
+    w.scan_scratch = (uint64_t *)take(scan_scratch_words(n) * 8);
+    w.blk_size = (uint64_t *)take((max_blocks + 1) * 8);
+    w.blk_scan = (uint64_t *)take((max_blocks + 1) * 8);
+    w.scan_scratch2 = (uint64_t *)take(scan_scratch_words(max_blocks) * 8);
+    w.total = off;
+    return w;
+}
+size_t stream_pack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total) {
+    return carve_stream_pack(nullptr, n_streams, n_values_total / FIXED_LEN + n_streams).total;
+}
+
+__global__ void k_stream_nblk_pack(int kind, const uint64_t *__restrict__ elem_off, uint64_t n, uint64_t *__restrict__ nblk) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    nblk[s] = (stream_packed_values(kind, elem_off[s + 1] - elem_off[s]) + FIXED_LEN - 1) / FIXED_LEN;
+}
+
+template <int KIND>
+static hipError_t stream_pack_t(const uint64_t *d_values, const uint64_t *d_elem_off, uint64_t n, uint64_t n_values_total,
+                                uint8_t *d_bytes, uint64_t *d_byte_off, int32_t *d_status, uint64_t *d_result,
+                                void *d_ws, hipStream_t stream) {
+    const uint64_t maxb = n_values_total / FIXED_LEN + n;
+    StreamPackWs w = carve_stream_pack(d_ws, n, maxb);
+    hipError_t e = hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t g = (uint32_t)((n + 256) / 256);
+    if (n) {
+        k_stream_nblk_pack<<<g, 256, 0, stream>>>(KIND, d_elem_off, n, w.nblk);
+        k_stream_ext<<<g, 256, 0, stream>>>(KIND, d_elem_off, n, w.ext);
+    }
+    e = launch_exclusive_scan(w.nblk, n, w.blk_base, w.scan_scratch, stream);
+    if (e != hipSuccess) return e;
+    e = launch_exclusive_scan(w.ext, n, w.ext_scan, w.scan_scratch, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t gb = (uint32_t)((maxb + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
+    if (maxb) k_stream_sizes<KIND><<<gb, ENC_THREADS, 0, stream>>>(d_values, d_elem_off, w.blk_base, n, maxb, w.blk_size);
+    e = launch_exclusive_scan(w.blk_size, maxb, w.blk_scan, w.scan_scratch2, stream);
+    if (e != hipSuccess) return e;
+    k_stream_offsets<<<g, 256, 0, stream>>>(KIND, d_values, d_elem_off, w.blk_base, w.blk_scan, w.ext_scan, n, d_bytes,
+                                            d_byte_off, d_status, d_result);
+    if (maxb) k_stream_emit<KIND><<<gb, ENC_THREADS, 0, stream>>>(d_values, d_elem_off, w.blk_base, n, maxb, w.blk_scan,
+                                                                  d_byte_off, d_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_pack(int kind, const uint64_t *d_values, const uint64_t *d_elem_off, uint64_t n,
+                              uint64_t n_values_total, uint8_t *d_bytes, uint64_t *d_byte_off, int32_t *d_status,
+                              uint64_t *d_result, void *d_ws, hipStream_t stream) {
+    if (kind == CVEC_STREAM_F64_XOR)
+        return stream_pack_t<CVEC_STREAM_F64_XOR>(d_values, d_elem_off, n, n_values_total, d_bytes, d_byte_off, d_status,
+                                                  d_result, d_ws, stream);
+    return stream_pack_t<CVEC_STREAM_U64_DELTA>(d_values, d_elem_off, n, n_values_total, d_bytes, d_byte_off, d_status,
+                                                d_result, d_ws, stream);
 }
 
 // ---- launcher --------------------------------------------------------------------------------------------

@@ -1,0 +1,260 @@
+// cvec_stream.hip — the legacy NibblePack stream codecs for batches of streams:
+//   pack_u64_delta + DeltaSink        (reference src/nibblepacking.rs:15-23, :239-279)
+//   pack_f64_xor + DoubleXorSink      (src/nibblepacking.rs:29-45, :284-325, :392-400)
+//   pack_u64 / unpack                 (src/nibblepacking.rs:68-93, :364-377)
+// A stream has no section structure: its octets form one serial chain, and the decoded values go
+// through a true element-to-element prefix sum / prefix XOR.  Unpack = index (one lane per stream
+// walks its octet chain once and cuts it into blocks of 32 octets) -> the section kernel decodes
+// the blocks (K_RAW descriptors) -> per-block totals -> per-stream carries -> per-block wavefront
+// scan that writes the final values.  Pack = per-block sizes -> scans -> emit.
+#include "cvec_device.hpp"
+
+namespace cvec {
+
+hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_scratch,
+                                 hipStream_t stream);
+uint64_t scan_scratch_words(uint64_t n);
+hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, uint64_t n_blocks, uint32_t *sec_res,
+                                 uint64_t *d_out, hipStream_t stream);
+
+// values that go through NibblePack: all n for the delta codec, n - 1 for XOR (the first is stored raw)
+__device__ __host__ inline uint64_t packed_values(int kind, uint64_t n) {
+    return kind == CVEC_STREAM_F64_XOR ? (n ? n - 1 : 0) : n;
+}
+
+__global__ void k_stream_nblk(int kind, const uint64_t *__restrict__ elem_off, uint64_t n, uint64_t *__restrict__ nblk) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    nblk[s] = (packed_values(kind, elem_off[s + 1] - elem_off[s]) + FIXED_LEN - 1) / FIXED_LEN;
+}
+
+// ---- unpack ---------------------------------------------------------------------------------------
+// One lane per stream: the serial octet chain of `unpack` (src/nibblepacking.rs:364-377), with the
+// checks of nibble_unpack8 (:418, :425) and "an octet must end inside the stream".  Writes one
+// K_RAW descriptor per block of 32 octets.
+__global__ __launch_bounds__(64) void k_stream_index(int kind, const uint8_t *__restrict__ bytes,
+                                                     const uint64_t *__restrict__ byte_off,
+                                                     const uint64_t *__restrict__ elem_off,
+                                                     const uint64_t *__restrict__ blk_base, uint64_t n,
+                                                     uint64_t padded_bytes, uint64_t *__restrict__ desc,
+                                                     int32_t *__restrict__ status) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint64_t nval = elem_off[s + 1] - elem_off[s];
+    const uint64_t start = byte_off[s], end = byte_off[s + 1];
+    const uint64_t b0 = blk_base[s], nb = blk_base[s + 1] - b0;
+    int st = CVEC_OK;
+    uint64_t p = start;
+    if (kind == CVEC_STREAM_F64_XOR) {
+        if (nval < 1) st = CVEC_INPUT_TOO_SHORT;            // unpack_f64_xor asserts num_values >= 1 (:395)
+        else if (end - start < 8) st = CVEC_NOT_ENOUGH_SPACE; // the raw first value (:396)
+        p += 8;
+    }
+    const uint64_t noct = (packed_values(kind, nval) + 7) / 8;
+    uint64_t blk = 0, blk_start = p;
+    for (uint64_t o = 0; o < noct && st == CVEC_OK; o++) {
+        if ((o & 31) == 0) blk_start = p;
+        if (p >= end) { st = CVEC_NOT_ENOUGH_SPACE; break; }
+        // one 2-byte read per octet, pulled back inside the padded allocation at the very end
+        const uint64_t a = p + 2 <= padded_bytes ? p : padded_bytes - 2;
+        const uint32_t hw = (uint32_t)(*(const u16u *)(bytes + a)) >> (8 * (uint32_t)(p - a));
+        const uint32_t mask = hw & 0xffu;
+        uint64_t size = 1;
+        if (mask) {
+            if (end - p < 2) { st = CVEC_NOT_ENOUGH_SPACE; break; }
+            const uint32_t nn = ((hw >> 12) & 0xfu) + 1;
+            size = 2 + ((nn * __popc(mask) + 1) >> 1);
+            if (size > end - p) { st = CVEC_NOT_ENOUGH_SPACE; break; }
+        }
+        p += size;
+        if ((o & 31) == 31 || o + 1 == noct) desc[b0 + blk++] = desc_pack(blk_start, (uint32_t)(p - blk_start), K_RAW);
+    }
+    for (; blk < nb; blk++) desc[b0 + blk] = desc_pack(p < end ? p : end, 0, K_SKIP);
+    status[s] = st;
+}
+
+// Slots past the real block count (known only on the device) become empty K_SKIP descriptors at
+// the end of the blob, which keeps the descriptor offsets non-decreasing.
+__global__ void k_fill_skip(const uint64_t *__restrict__ n_real, uint64_t fill_off, uint64_t *__restrict__ desc,
+                            uint64_t max_blocks) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < max_blocks && b >= *n_real) desc[b] = desc_pack(fill_off, 0, K_SKIP);
+}
+
+// Combine of the stream's running state: wrapping sum (DeltaSink) or XOR (DoubleXorSink).
+template <int KIND> __device__ inline uint64_t comb(uint64_t a, uint64_t b) {
+    return KIND == CVEC_STREAM_F64_XOR ? a ^ b : a + b;
+}
+
+// Inclusive wave scan of one value per lane.
+template <int KIND> __device__ inline uint64_t wave_scan_incl(uint64_t x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d, 64);
+        if (lane >= d) x = comb<KIND>(x, y);
+    }
+    return x;
+}
+
+// One wave per block: lane L owns elements 4L..4L+3 of the block (element order, not octet lanes).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_stream_totals(const uint64_t *__restrict__ raw, uint64_t n_blocks,
+                                                       uint64_t *__restrict__ totals) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t blk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    const uint4 *p = (const uint4 *)(raw + blk * FIXED_LEN + 4 * lane);
+    const uint4 a = p[0], b = p[1];
+    uint64_t t = comb<KIND>(comb<KIND>(((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z),
+                            comb<KIND>(((uint64_t)b.y << 32) | b.x, ((uint64_t)b.w << 32) | b.z));
+    t = wave_scan_incl<KIND>(t, lane);
+    if (lane == 63) totals[blk] = t;
+}
+
+// One lane per stream: exclusive running state at the start of each of its blocks.  The octets of
+// the last block past the stream's values are zero padding of the encoder (they do not change the
+// state), and a failed stream's blocks are never read back.
+template <int KIND>
+__global__ void k_stream_carries(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ byte_off,
+                                 const uint64_t *__restrict__ blk_base, uint64_t n,
+                                 const int32_t *__restrict__ status, const uint64_t *__restrict__ totals,
+                                 uint64_t *__restrict__ carries) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    uint64_t acc = 0;
+    if (KIND == CVEC_STREAM_F64_XOR && status[s] == CVEC_OK) acc = *(const u64u *)(bytes + byte_off[s]);
+    for (uint64_t b = blk_base[s]; b < blk_base[s + 1]; b++) {
+        carries[b] = acc;
+        acc = comb<KIND>(acc, totals[b]);
+    }
+}
+
+// One wave per block: in-block inclusive scan in element order + the block's carry -> final values,
+// written compactly (stream s occupies out[elem_off[s] .. elem_off[s+1])).
+template <int KIND>
+__global__ __launch_bounds__(256) void k_stream_scan_write(const uint64_t *__restrict__ raw,
+                                                           const uint64_t *__restrict__ blk_base,
+                                                           const uint64_t *__restrict__ elem_off, uint64_t n,
+                                                           uint64_t n_blocks, const uint64_t *__restrict__ carries,
+                                                           const int32_t *__restrict__ status,
+                                                           uint64_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t blk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    // stream of this block: last s with blk_base[s] <= blk
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (blk_base[mid] <= blk) lo = mid; else hi = mid;
+    }
+    const uint64_t s = lo;
+    if (status[s] != CVEC_OK) return;
+    const uint64_t nval = elem_off[s + 1] - elem_off[s];
+    const uint64_t shift = KIND == CVEC_STREAM_F64_XOR ? 1 : 0;
+    const uint64_t first = (blk - blk_base[s]) * FIXED_LEN; // index among the packed values
+    const uint4 *p = (const uint4 *)(raw + blk * FIXED_LEN + 4 * lane);
+    const uint4 a = p[0], b = p[1];
+    uint64_t x[4] = {((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, ((uint64_t)b.y << 32) | b.x,
+                     ((uint64_t)b.w << 32) | b.z};
+    x[1] = comb<KIND>(x[0], x[1]); x[2] = comb<KIND>(x[1], x[2]); x[3] = comb<KIND>(x[2], x[3]);
+    const uint64_t incl = wave_scan_incl<KIND>(x[3], lane);
+    uint64_t excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0;
+    const uint64_t base = comb<KIND>(carries[blk], excl);
+    uint64_t *o = out + elem_off[s] + shift + first + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (shift + first + 4 * lane + i < nval) o[i] = comb<KIND>(base, x[i]);
+    if (KIND == CVEC_STREAM_F64_XOR && first == 0 && lane == 0) out[elem_off[s]] = carries[blk]; // the raw first value
+}
+
+// A stream without any packed value (XOR stream of one value) has no block: its first value is
+// written here; also folds the statuses into the result block.
+template <int KIND>
+__global__ void k_stream_finish(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ byte_off,
+                                const uint64_t *__restrict__ blk_base, const uint64_t *__restrict__ elem_off, uint64_t n,
+                                const uint32_t *__restrict__ sec_res, int32_t *__restrict__ status,
+                                uint64_t *__restrict__ out, uint64_t *__restrict__ result) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    int st = status[s];
+    for (uint64_t b = blk_base[s]; b < blk_base[s + 1] && st == CVEC_OK; b++)
+        if (sec_res[b] >> 16) st = (int)(sec_res[b] >> 16);
+    status[s] = st;
+    if (st == CVEC_OK) {
+        if (KIND == CVEC_STREAM_F64_XOR && blk_base[s + 1] == blk_base[s]) out[elem_off[s]] = *(const u64u *)(bytes + byte_off[s]);
+        atomicAdd((unsigned long long *)&result[0], (unsigned long long)(elem_off[s + 1] - elem_off[s]));
+    } else {
+        atomicAdd((unsigned long long *)&result[1], 1ull);
+        atomicMax((unsigned long long *)&result[2], (unsigned long long)st);
+    }
+}
+
+struct StreamUnpackWs {
+    uint64_t *nblk, *blk_base, *scan_scratch, *desc, *raw, *totals, *carries;
+    uint32_t *sec_res;
+    size_t total;
+};
+static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+static StreamUnpackWs carve_unpack(void *base, uint64_t n, uint64_t max_blocks) {
+    StreamUnpackWs w;
+    uint8_t *b = (uint8_t *)base;
+    size_t off = 0;
+    w.nblk = (uint64_t *)(b + off); off += al256((n + 1) * 8);
+    w.blk_base = (uint64_t *)(b + off); off += al256((n + 1) * 8);
+    w.scan_scratch = (uint64_t *)(b + off); off += al256(scan_scratch_words(n) * 8);
+    w.desc = (uint64_t *)(b + off); off += al256((max_blocks + 1) * 8);
+    w.sec_res = (uint32_t *)(b + off); off += al256((max_blocks + 1) * 4);
+    w.totals = (uint64_t *)(b + off); off += al256((max_blocks + 1) * 8);
+    w.carries = (uint64_t *)(b + off); off += al256((max_blocks + 1) * 8);
+    w.raw = (uint64_t *)(b + off); off += al256(max_blocks * FIXED_LEN * 8 + 64);
+    w.total = off;
+    return w;
+}
+// blocks of a batch: at most one partial block per stream
+static inline uint64_t max_blocks_of(uint64_t n_streams, uint64_t n_values_total) {
+    return n_values_total / FIXED_LEN + n_streams;
+}
+size_t stream_unpack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total) {
+    return carve_unpack(nullptr, n_streams, max_blocks_of(n_streams, n_values_total)).total;
+}
+
+template <int KIND>
+static hipError_t unpack_t(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                           const uint64_t *d_elem_off, uint64_t n, uint64_t n_values_total, uint64_t *d_out,
+                           int32_t *d_status, uint64_t *d_result, void *d_ws, hipStream_t stream) {
+    const uint64_t maxb = max_blocks_of(n, n_values_total);
+    StreamUnpackWs w = carve_unpack(d_ws, n, maxb);
+    hipError_t e = hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
+    if (e != hipSuccess || n == 0) return e;
+    const uint32_t g = (uint32_t)((n + 255) / 256);
+    k_stream_nblk<<<g, 256, 0, stream>>>(KIND, d_elem_off, n, w.nblk);
+    e = launch_exclusive_scan(w.nblk, n, w.blk_base, w.scan_scratch, stream);
+    if (e != hipSuccess) return e;
+    k_stream_index<<<(uint32_t)((n + 63) / 64), 64, 0, stream>>>(KIND, d_bytes, d_byte_off, d_elem_off, w.blk_base, n,
+                                                                 (n_bytes + 15) & ~15ull, w.desc, d_status);
+    // The block count is only known on the device; the section kernel runs over the upper bound and
+    // skips the slots past the real count (their descriptors are K_SKIP).
+    k_fill_skip<<<(uint32_t)((maxb + 255) / 256), 256, 0, stream>>>(w.blk_base + n, n_bytes, w.desc, maxb);
+    e = launch_raw_blocks_u64(d_bytes, w.desc, maxb, w.sec_res, w.raw, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t gb = (uint32_t)((maxb + 3) / 4);
+    k_stream_totals<KIND><<<gb, 256, 0, stream>>>(w.raw, maxb, w.totals);
+    k_stream_carries<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, n, d_status, w.totals, w.carries);
+    k_stream_finish<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, d_elem_off, n, w.sec_res, d_status, d_out,
+                                                 d_result);
+    k_stream_scan_write<KIND><<<gb, 256, 0, stream>>>(w.raw, w.blk_base, d_elem_off, n, maxb, w.carries, d_status, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_unpack(int kind, const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                const uint64_t *d_elem_off, uint64_t n, uint64_t n_values_total, uint64_t *d_out,
+                                int32_t *d_status, uint64_t *d_result, void *d_ws, hipStream_t stream) {
+    if (kind == CVEC_STREAM_F64_XOR)
+        return unpack_t<CVEC_STREAM_F64_XOR>(d_bytes, d_byte_off, n_bytes, d_elem_off, n, n_values_total, d_out, d_status,
+                                             d_result, d_ws, stream);
+    return unpack_t<CVEC_STREAM_U64_DELTA>(d_bytes, d_byte_off, n_bytes, d_elem_off, n, n_values_total, d_out, d_status,
+                                           d_result, d_ws, stream);
+}
+
+} // namespace cvec

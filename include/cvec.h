@@ -193,6 +193,33 @@ cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t 
                             uint64_t *d_sec_base, uint64_t *d_result, void *d_workspace, size_t workspace_bytes,
                             void *stream);
 
+/* ---- legacy NibblePack stream codecs (batches of streams) ------------------------------------- */
+
+/* pack_u64_delta (src/nibblepacking.rs:15-23: deltas clipped at 0, then pack_u64 :68-93) or
+ * pack_f64_xor (:29-45: first value raw, then XOR with the predecessor) for n_streams streams;
+ * stream s's values are d_values[elem_off[s] .. elem_off[s+1]) as 64-bit patterns.  Writes the
+ * streams back to back into d_bytes (16-byte aligned, capacity >= cvec_stream_max_packed_bytes) and
+ * d_byte_off[n_streams+1]; d_result[0] = bytes written.  d_status (nullable): per stream, only
+ * InputTooShort for an empty XOR stream (src/nibblepacking.rs:37). */
+enum { CVEC_STREAM_U64_DELTA = 1, CVEC_STREAM_F64_XOR = 2 };
+size_t cvec_stream_max_packed_bytes(int32_t kind, uint64_t n_streams, uint64_t n_values_total);
+size_t cvec_stream_pack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total);
+cvec_status cvec_stream_pack_dev(int32_t kind, const uint64_t *d_values, const uint64_t *d_elem_off,
+                                 uint64_t n_streams, uint64_t n_values_total, uint8_t *d_bytes, size_t bytes_cap,
+                                 uint64_t *d_byte_off, int32_t *d_status, uint64_t *d_result, void *d_workspace,
+                                 size_t workspace_bytes, void *stream);
+
+/* unpack into a DeltaSink (src/nibblepacking.rs:239-279, :364-377: running wrapping sum) or
+ * unpack_f64_xor into a DoubleXorSink (:284-325, :392-400: running XOR seeded with the raw first
+ * value): stream s decodes elem_off[s+1] - elem_off[s] values into d_out[elem_off[s] ...] (the
+ * zero padding of the last octet is not written).  d_bytes as for a batch (16-byte aligned, padded
+ * allocation).  d_status: n_streams int32; d_result[0] = values written, [1] = failed streams. */
+size_t cvec_stream_unpack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total);
+cvec_status cvec_stream_unpack_dev(int32_t kind, const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                   const uint64_t *d_elem_off, uint64_t n_streams, uint64_t n_values_total,
+                                   uint64_t *d_out, int32_t *d_status, uint64_t *d_result, void *d_workspace,
+                                   size_t workspace_bytes, void *stream);
+
 /* ---- host-buffer convenience (what a Rust ffi.rs shim behind the unchanged crate API calls) -- */
 /* Each call uploads through pinned staging, runs the _dev operation and downloads the result.   */
 

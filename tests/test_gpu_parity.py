@@ -373,6 +373,67 @@ def test_multi_vector_filter_and_positions_vs_oracle(cv, oracle):
         assert np.array_equal(pos[int(off[v]):int(off[v + 1])].astype(np.uint64), want), v
 
 
+def test_legacy_stream_codecs_vs_oracle(cv, oracle):
+    """pack_u64_delta / DeltaSink and pack_f64_xor / DoubleXorSink (src/nibblepacking.rs:15-45, :239-325,
+    :392-400) over batches of ragged streams: packed bytes and unpacked values equal the oracle's."""
+    rng = np.random.default_rng(19)
+    # --- delta: increasing counters (with a few decreases, which the packer clips to 0, :18) -----------
+    streams = []
+    for n in [1, 7, 8, 9, 255, 256, 257, 1000, 5000, 0, 33]:
+        inc = rng.integers(0, 1 << int(rng.integers(1, 40)), size=n).astype(np.uint64)
+        if n > 20:
+            inc[rng.integers(0, n, size=n // 4)] = 0
+        v = np.cumsum(inc, dtype=np.uint64)
+        if n > 50:
+            v[n // 2] = v[n // 2 - 1] - np.uint64(1)                     # a decrease
+        streams.append(v)
+    streams.append(np.array([1, 1 << 63, (1 << 64) - 1], dtype=np.uint64))
+    eo = np.concatenate([[0], np.cumsum([s.size for s in streams])]).astype(np.uint64)
+    vals = np.concatenate(streams) if streams else np.zeros(0, np.uint64)
+    blob, bo, st = cv.stream.pack_batch("u64_delta", vals, eo)
+    assert not st.any()
+    for i, sv in enumerate(streams):
+        want = oracle.pack_u64_delta(sv)
+        assert blob[int(bo[i]):int(bo[i + 1])].tobytes() == bytes(want), i
+    got, st = cv.stream.unpack_batch("u64_delta", blob, bo, eo)
+    assert not st.any()
+    for i, sv in enumerate(streams):
+        want = oracle.unpack_u64_delta(blob[int(bo[i]):int(bo[i + 1])], sv.size)[0][:sv.size] if sv.size else sv
+        assert np.array_equal(got[int(eo[i]):int(eo[i + 1])], want), i
+    # --- f64 XOR -----------------------------------------------------------------------------------------
+    fstreams = []
+    for n in [1, 2, 8, 9, 10, 257, 258, 3000]:
+        x = np.cumsum(rng.normal(size=n)) + 100.0
+        if n > 100:
+            x[50:80] = x[49]                                             # repeated values: zero octets
+        fstreams.append(x.astype(np.float64))
+    fstreams.append(np.array([0.0, -0.0, np.nan, np.inf, 1e-310], dtype=np.float64))
+    feo = np.concatenate([[0], np.cumsum([s.size for s in fstreams])]).astype(np.uint64)
+    fvals = np.concatenate(fstreams)
+    blob, bo, st = cv.stream.pack_batch("f64_xor", fvals, feo)
+    assert not st.any()
+    for i, sv in enumerate(fstreams):
+        assert blob[int(bo[i]):int(bo[i + 1])].tobytes() == bytes(oracle.pack_f64_xor(sv)), i
+    got, st = cv.stream.unpack_batch("f64_xor", blob, bo, feo)
+    assert not st.any()
+    assert got.view(np.uint64).tobytes() == fvals.view(np.uint64).tobytes()          # bitwise round trip
+    for i, sv in enumerate(fstreams):
+        want = oracle.unpack_f64_xor(blob[int(bo[i]):int(bo[i + 1])], sv.size)[0][:sv.size]
+        assert np.array_equal(got[int(feo[i]):int(feo[i + 1])].view(np.uint64), want.view(np.uint64)), i
+    # --- errors: an empty XOR stream cannot be packed (:37); truncated streams report NotEnoughSpace ------
+    _, _, st = cv.stream.pack_batch("f64_xor", np.zeros(3), np.array([0, 0, 3], dtype=np.uint64))
+    assert list(st) == [2, 0]
+    cut = np.concatenate([blob[int(bo[7]):int(bo[8]) - 5], blob[int(bo[2]):int(bo[3])]])
+    cbo = np.array([0, int(bo[8] - bo[7]) - 5, int(bo[8] - bo[7]) - 5 + int(bo[3] - bo[2])], dtype=np.uint64)
+    ceo = np.array([0, fstreams[7].size, fstreams[7].size + fstreams[2].size], dtype=np.uint64)
+    got, st = cv.stream.unpack_batch("f64_xor", cut, cbo, ceo)
+    assert st[0] == 1 and st[1] == 0
+    assert np.array_equal(got[int(ceo[1]):].view(np.uint64), fstreams[2].view(np.uint64))
+    # the single-stream mirror of the reference's function names
+    enc = cv.stream.pack_u64_delta([0, 1000, 1001, 1002, 1003, 2005, 2010, 3034, 4045, 5056, 6067, 7078])
+    assert list(cv.stream.unpack_u64_delta(enc, 12)) == [0, 1000, 1001, 1002, 1003, 2005, 2010, 3034, 4045, 5056, 6067, 7078]
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
