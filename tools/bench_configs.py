@@ -48,8 +48,30 @@ def run(name, tname, kind, nvec, length, pred, add_const):
                       "filter_GBs": round(raw / t_fil / 1e9, 1), "filter_matches": got}), flush=True)
 
 
+def run_streams(nstreams, length):
+    """Legacy delta stream codec (benches/bench.rs:71-93 shape: increasing u64 counters)."""
+    from compressed_vec_amd import stream as st
+    g = torch.Generator(device="cuda").manual_seed(5)
+    inc = torch.randint(0, 1000, (nstreams * length,), device="cuda", dtype=torch.int64, generator=g)
+    vals = torch.cumsum(inc.view(nstreams, length), dim=1).reshape(-1).contiguous()
+    eo = torch.arange(nstreams + 1, device="cuda", dtype=torch.int64) * length
+    total = nstreams * length
+    raw = total * 8
+    d_bytes, d_bo, _, d_res = st.pack_device("u64_delta", vals, eo, total)
+    nbytes = int(d_res[0].item())
+    t_pack = timed(lambda: st.pack_device("u64_delta", vals, eo, total), 5)
+    out = torch.empty(total, dtype=torch.int64, device="cuda")
+    ws = torch.empty(cv.lib().cvec_stream_unpack_workspace_bytes(nstreams, total), dtype=torch.uint8, device="cuda")
+    t_unpack = timed(lambda: st.unpack_device("u64_delta", d_bytes, d_bo, nbytes, eo, total, out, ws), 5)
+    assert torch.equal(out, vals)
+    print(json.dumps({"config": "legacy u64 delta streams", "streams": nstreams, "stream_len": length,
+                      "raw_MiB": raw >> 20, "compressed_B_per_elem": round(nbytes / total, 3),
+                      "pack_GBs": round(raw / t_pack / 1e9, 1), "unpack_GBs": round(raw / t_unpack / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 26214          # x 10000 x 4 B = 1 GiB
     run("cfg1 u32 dense", "u32", "u32_dense", n, 10000, 3, 7)
     run("cfg3 f32 xor", "f32", "f32_xor", n, 10000, 3.0, 2.5)
     run("cfg4 u64 delta", "u64", "u64_delta", n // 2, 10000, 100003, 5)
+    run_streams(n // 2, 10000)
