@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "cvec_device.hpp"
@@ -216,7 +217,9 @@ constexpr uint32_t REGION_SPAN = REGION_BYTES - 64;
 constexpr int SEC_WAVES = 4;
 constexpr int SEC_THREADS = SEC_WAVES * 64;
 
-enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2 };
+// MODE_FILTER_BITS: count only, one predicate value whose IEEE == is the same as equality of the bit
+// patterns (any integer; a float that is neither zero nor NaN): matching needs no compare instruction.
+enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2, MODE_FILTER_BITS = 3 };
 
 struct SecShared {
     __attribute__((aligned(16))) uint8_t data[SEC_WAVES][REGION_BYTES];
@@ -316,83 +319,129 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     U st0 = 0, st1 = 0; // XOR state of the lane's two element columns / the additive base
     if constexpr (ETYPE == CVEC_F32) { st0 = st1 = isconst ? v : (U)0; }
     const U base = (isconst || isdelta) ? v : (U)0;
+    // MODE_FILTER_BITS: the predicate's bits are XORed into the state (f32) or moved to the other side of
+    // the Delta add (integers), so that an element matches iff its word is zero
+    U tgt = 0;
+    if constexpr (MODE == MODE_FILTER_BITS) {
+        if constexpr (ETYPE == CVEC_F32) { st0 ^= (U)pa.v[0]; st1 = st0; }
+        else tgt = (U)pa.v[0] - base;
+    }
+    uint32_t mism = 0;
     const uint32_t lowmask = (1u << (2 * q)) - 1u;
     uint32_t cnt = 0, hmax = 0, racc = 0;
     const uint32_t q2 = 2 * q;
     U *op = (U *)out_ + slot * FIXED_LEN + 2 * q;
     const bool addc = sa.add_const != 0;
 
+    // The loop is software-pipelined by one octet: iteration k runs the front half of octet k (walk
+    // chain, header reads of octet k+1, address + reads of the lane's fields, per-octet constants) and
+    // the back half of octet k-1 (extraction, XOR / Delta, epilogue), so every LDS read has a whole
+    // iteration to land and the serial chain header -> size -> next header is as short as it can be.
+    // All LDS reads are inline asm with counted waits (LDS returns in order): per iteration the wave
+    // issues 2 header reads, then NDATA field reads.
+    constexpr int NDATA = W == 4 ? 2 : 3;
+    struct Oct { // what the back half needs of an octet
+        uint64_t d01, d23;
+        uint32_t d2, d4, s, sh1, sm0, sm1, t4;
+        U fm;
+    };
     uint32_t pa_ = lds_base + p0;
     uint32_t mask, nw;
     asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(mask), "=&v"(nw)
                  : "v"(pa_)
                  : "memory");
-#pragma unroll 4
-    for (int k = 0; k < FIXED_LEN / 8; k++) {
-        // ---- address of the lane's two fields in the current octet; their reads go out first ----------------
-        const uint32_t hn = nw >> 4;        // n - 1
-        const uint32_t n4 = (hn << 2) + 4u; // field width in bits
-        const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
-        const uint32_t A = pa_ + 2u + (b0 >> 3);
-        const uint32_t s = (A << 3) | (b0 & 4u); // funnel shift; only bits 4:0 are used
-        const uint32_t qa = A & ~3u;
-        uint64_t d01;
-        uint32_t d2, d3 = 0, d4 = 0;
-        if constexpr (W == 4) {
-            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
-                         : "=&v"(d01), "=&v"(d2)
-                         : "v"(qa)
-                         : "memory");
-        } else {
-            lds_u32p qd = (lds_u32p)(uintptr_t)qa;
-            d01 = (uint64_t)qd[0] | ((uint64_t)qd[1] << 32);
-            d2 = qd[2]; d3 = qd[3]; d4 = qd[4];
-        }
-        // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2; then the reads of the next
-        //      octet (after the last one: a harmless read of the bytes that follow).  mask and nw pass
-        //      through the statement so that the unpacking below is scheduled behind it. -------------------------
+
+    // front half of the octet whose header is in (mask, nw); leaves the next header in flight
+    auto front = [&](Oct &o, uint32_t &mask_n, uint32_t &nw_n) {
+        // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2; then the reads of the
+        //      next octet's header (after the last octet: a harmless read of the bytes that follow) ------
+        const uint32_t hn = nw >> 4; // n - 1
         const uint32_t pc = __popc(mask);
         const uint32_t a3 = (uint32_t)__umul24(min(mask, 1u), 3u) + (pc + 2u);
+        const uint32_t pa_cur = pa_;
         pa_ += ((uint32_t)__umul24(hn, pc) + a3) >> 1;
-        uint32_t mask_n, nw_n;
+        // mask and nw pass through the statement so that everything below is scheduled behind it
         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1"
                      : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
                      : "v"(pa_)
                      : "memory");
+        // ---- address of the lane's two fields, their reads ---------------------------------------------
+        uint32_t n4;                        // field width in bits, 4 * (hn + 1), as ONE instruction
+        asm("v_lshl_add_u32 %0, %1, 2, 4" : "=v"(n4) : "v"(nw >> 4));
+        const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
+        const uint32_t A = pa_cur + 2u + (b0 >> 3);
+        o.s = (A << 3) | (b0 & 4u); // funnel shift; only bits 4:0 are used
+        const uint32_t qa = A & ~3u;
+        if constexpr (W == 4) {
+            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
+                         : "=&v"(o.d01), "=&v"(o.d2)
+                         : "v"(qa)
+                         : "memory");
+        } else {
+            asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16"
+                         : "=&v"(o.d01), "=&v"(o.d23), "=&v"(o.d4)
+                         : "v"(qa)
+                         : "memory");
+        }
+        // ---- per-octet constants ---------------------------------------------------------------------------
         if constexpr (W == 4 && CAREFUL) hmax = max(hmax, mask ? (nw >> 4) : 0u);
-        // ---- per-octet constants, in the shadow of both reads ----------------------------------------------------
-        uint32_t t4 = (nw & 15u) << 2; // trailing zero bits
-        uint32_t sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
-        uint32_t sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
-        if constexpr (W == 4 && !CAREFUL) racc |= nw & (sm0 | sm1); // the quad's lanes cover every stored element
-        U x0, x1;
+        o.t4 = nw << 2; // trailing zero bits (a 32-bit shift uses bits 4:0 of its count; bits 5:4 only matter to CAREFUL and 64-bit)
+        o.sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
+        o.sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
+        if constexpr (W == 4 && !CAREFUL) racc |= nw & (o.sm0 | o.sm1); // the quad's lanes cover every stored element
+        o.sh1 = n4 & o.sm0; // the second field lies n4 bits further on if the first one is stored
         if constexpr (W == 4) {
             // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
-            uint32_t fm = (CAREFUL && t4 >= 32u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
-            uint32_t sh1 = n4 & sm0;
-            // the field reads have landed once only the two header reads are outstanding (LDS returns in
-            // order); the constants above pass through the statement so that they are computed ahead of it
-            asm volatile("s_waitcnt lgkmcnt(2)"
-                         : "+v"(d01), "+v"(d2), "+v"(fm), "+v"(sh1), "+v"(sm0), "+v"(sm1), "+v"(t4), "+v"(racc)
-                         :
-                         : "memory");
-            const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
-            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s), hi = __builtin_amdgcn_alignbit(d2, d1, s);
-            const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh1);
-            x0 = ((lo & fm) & sm0) << (t4 & 31u);
-            x1 = ((w1 & fm) & sm1) << (t4 & 31u);
+            o.fm = (CAREFUL && (nw & 8u)) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
         } else {
-            const uint32_t d0 = (uint32_t)d01, d1 = (uint32_t)(d01 >> 32);
-            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, s), w1 = __builtin_amdgcn_alignbit(d2, d1, s),
-                           w2 = __builtin_amdgcn_alignbit(d3, d2, s), w3 = __builtin_amdgcn_alignbit(d4, d3, s);
-            const uint64_t fm = ~0ull >> ((64u - n4) & 63u);
+            o.fm = ~0ull >> ((64u - n4) & 63u);
+        }
+    };
+
+    // back half of octet k: `newer` LDS reads were issued after its field reads
+    auto back = [&](Oct &o, int k, auto newer) {
+        U x0, x1;
+        if constexpr (W == 4) {
+            // the octet's values pass through the wait: the compiler may neither use the loaded registers
+            // ahead of it nor move the extraction somewhere else
+            asm volatile("s_waitcnt lgkmcnt(%c9)"
+                         : "+v"(o.d01), "+v"(o.d2), "+v"(o.fm), "+v"(o.sh1), "+v"(o.sm0), "+v"(o.sm1), "+v"(o.s), "+v"(o.t4),
+                           "+v"(racc)
+                         : "i"(decltype(newer)::value)
+                         : "memory");
+            const uint32_t d0 = (uint32_t)o.d01, d1 = (uint32_t)(o.d01 >> 32);
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, o.s), hi = __builtin_amdgcn_alignbit(o.d2, d1, o.s);
+            const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> o.sh1);
+            x0 = ((lo & o.fm) & o.sm0) << (o.t4 & 31u);
+            x1 = ((w1 & o.fm) & o.sm1) << (o.t4 & 31u);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(%c7)"
+                         : "+v"(o.d01), "+v"(o.d23), "+v"(o.d4), "+v"(o.fm), "+v"(o.sh1), "+v"(o.sm0), "+v"(o.sm1)
+                         : "i"(decltype(newer)::value)
+                         : "memory");
+            const uint32_t d0 = (uint32_t)o.d01, d1 = (uint32_t)(o.d01 >> 32), d2 = (uint32_t)o.d23,
+                           d3 = (uint32_t)(o.d23 >> 32);
+            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, o.s), w1 = __builtin_amdgcn_alignbit(d2, d1, o.s),
+                           w2 = __builtin_amdgcn_alignbit(d3, d2, o.s), w3 = __builtin_amdgcn_alignbit(o.d4, d3, o.s);
             const uint64_t f0 = ((uint64_t)w1 << 32) | w0;
-            // second field: n4 bits further on if the first one is stored (n4 up to 64)
             const unsigned __int128 win = ((unsigned __int128)(((uint64_t)w3 << 32) | w2) << 64) | f0;
-            const uint64_t f1 = (uint64_t)(win >> (n4 & sm0));
-            x0 = ((f0 & fm) & (uint64_t)(int64_t)(int32_t)sm0) << t4;
-            x1 = ((f1 & fm) & (uint64_t)(int64_t)(int32_t)sm1) << t4;
+            const uint64_t f1 = (uint64_t)(win >> o.sh1);
+            x0 = ((f0 & o.fm) & (uint64_t)(int64_t)(int32_t)o.sm0) << (o.t4 & 60u);
+            x1 = ((f1 & o.fm) & (uint64_t)(int64_t)(int32_t)o.sm1) << (o.t4 & 60u);
+        }
+        if constexpr (MODE == MODE_FILTER_BITS) {
+            if constexpr (ETYPE == CVEC_F32) { st0 ^= x0; st1 ^= x1; x0 = st0; x1 = st1; }
+            else { x0 ^= tgt; x1 ^= tgt; }
+            // zero word = match: count the mismatches (min(x, 1)), no compare / carry instructions
+            // (as asm: the compiler rewrites min(x, 1) into a compare + select + add-with-carry chain)
+            uint32_t w0, w1, m0, m1;
+            if constexpr (W == 4) { w0 = (uint32_t)x0; w1 = (uint32_t)x1; }
+            else { w0 = (uint32_t)x0 | (uint32_t)(x0 >> 32); w1 = (uint32_t)x1 | (uint32_t)(x1 >> 32); }
+            asm("v_min_u32 %0, 1, %1" : "=v"(m0) : "v"(w0));
+            asm("v_min_u32 %0, 1, %1" : "=v"(m1) : "v"(w1));
+            mism += m0 + m1;
+            return;
         }
         if constexpr (ETYPE == CVEC_F32) {
             st0 ^= x0; st1 ^= x1;
@@ -429,11 +478,25 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
                 else *(uint4 *)(op + 8 * k) = make_uint4((uint32_t)x0, (uint32_t)(x0 >> 32), (uint32_t)x1, (uint32_t)(x1 >> 32));
             }
         }
-        // the step's results pass through the wait so that the work above is issued ahead of it
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mask_n), "+v"(nw_n), "+v"(cnt), "+v"(st0), "+v"(st1) : : "memory");
-        mask = mask_n;
-        nw = nw_n;
+    };
+
+    Oct prev, cur;
+    uint32_t mask_n, nw_n;
+    front(prev, mask_n, nw_n);
+    asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(mask_n), "+v"(nw_n) : "i"(NDATA) : "memory"); // header of octet 1
+    mask = mask_n; nw = nw_n;
+#pragma unroll 4
+    for (int k = 1; k < FIXED_LEN / 8; k++) {
+        front(cur, mask_n, nw_n);
+        // octet k-1: behind its field reads came 2 header reads and NDATA field reads
+        back(prev, k - 1, std::integral_constant<int, 2 + NDATA>());
+        prev = cur;
+        // the next header has landed once only this iteration's field reads are outstanding; the
+        // step's results pass through the wait so that the work above is issued ahead of it
+        asm volatile("s_waitcnt lgkmcnt(%c6)" : "+v"(mask_n), "+v"(nw_n), "+v"(cnt), "+v"(mism), "+v"(st0), "+v"(st1) : "i"(NDATA) : "memory");
+        mask = mask_n; nw = nw_n;
     }
+    back(prev, FIXED_LEN / 8 - 1, std::integral_constant<int, 0>());
     // ---- per-section result ------------------------------------------------------------------------------------
     uint32_t status = 0;
     if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
@@ -443,6 +506,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     if constexpr (MODE == MODE_DECODE) {
         count = FIXED_LEN;
     } else {
+        if constexpr (MODE == MODE_FILTER_BITS) cnt = 2 * (FIXED_LEN / 8) - mism; // the lane saw 64 elements
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
         // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
@@ -521,7 +585,7 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
     u32x4 R[REGION_PIECES];
     auto issue_loads = [&](const ChunkPlan &c) {
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)(c.nch * 16u), 0x00020000);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)(sa._pad == 5 ? 0u : c.nch * 16u), 0x00020000);
 #pragma unroll
         for (int i = 0; i < REGION_PIECES; i++)
             R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 2 /* nt: read once */);
@@ -693,7 +757,8 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).
         static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 1; }();
-        const uint64_t nwaves_max = 256ull * 2 * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
+        static const int wgcu = [] { const char *e = getenv("CVEC_WG_PER_CU"); return e ? atoi(e) : 2; }();
+        const uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
         uint64_t per = (ns + nwaves_max - 1) / nwaves_max;
         per = (per + TILE - 1) / TILE * TILE;
         if (per < 2 * TILE) per = 2 * TILE;
@@ -707,7 +772,14 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
     k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
         if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);
         else if (d_masks) { if (single) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, true); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, false); }
-        else { if (single) CVEC_LAUNCH_SEC(MODE_FILTER, true); else CVEC_LAUNCH_SEC(MODE_FILTER, false); }
+        else if (single) {
+            // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN
+            const uint32_t fb = (uint32_t)pa.v[0];
+            const bool bits_ok = ETYPE != CVEC_F32 || ((fb & 0x7fffffffu) != 0 && (fb & 0x7fffffffu) <= 0x7f800000u);
+            if (bits_ok) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, true); else CVEC_LAUNCH_SEC(MODE_FILTER, true);
+        } else {
+            CVEC_LAUNCH_SEC(MODE_FILTER, false);
+        }
 #undef CVEC_LAUNCH_SEC
     }
 }

@@ -27,8 +27,15 @@ def timed(fn, iters=10):
 def run(name, tname, kind, nvec, length, pred, add_const):
     chunks = []
     for c0 in range(0, nvec, 4096):
-        chunks.append(synth.batch_values_torch(kind, min(4096, nvec - c0), length, v_first=c0)[0])
+        chunks.append(synth.batch_values_torch("u32_dense" if kind == "u32_sparse" else kind, min(4096, nvec - c0),
+                                               length, v_first=c0)[0])
     vals = torch.cat(chunks)
+    if kind == "u32_sparse":
+        # benches/bench.rs:160-170: two runs of 50 values in a vector of nulls (zeros)
+        keep = torch.zeros(length, dtype=torch.bool, device="cuda")
+        keep[2475:2525] = True
+        keep[7475:7525] = True
+        vals = torch.where(keep.repeat(nvec), vals, torch.zeros_like(vals))
     eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * length
     raw = vals.numel() * vals.element_size()
     batch = cv.encode_device(tname, vals, eo)
@@ -72,6 +79,7 @@ def run_streams(nstreams, length):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 26214          # x 10000 x 4 B = 1 GiB
     run("cfg1 u32 dense", "u32", "u32_dense", n, 10000, 3, 7)
+    run("cfg2 u32 sparse", "u32", "u32_sparse", n, 10000, 15, 7)
     run("cfg3 f32 xor", "f32", "f32_xor", n, 10000, 3.0, 2.5)
     run("cfg4 u64 delta", "u64", "u64_delta", n // 2, 10000, 100003, 5)
     run_streams(n // 2, 10000)
