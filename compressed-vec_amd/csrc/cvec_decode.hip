@@ -485,7 +485,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     front(prev, mask_n, nw_n);
     asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(mask_n), "+v"(nw_n) : "i"(NDATA) : "memory"); // header of octet 1
     mask = mask_n; nw = nw_n;
-#pragma unroll 4
+    // Fully unrolled on purpose: the field reads of an octet are in flight from one iteration to the
+    // next, and only straight-line code guarantees that the compiler never copies a register (a loop
+    // back-edge copy) whose asm load has not landed yet.
+#pragma unroll
     for (int k = 1; k < FIXED_LEN / 8; k++) {
         front(cur, mask_n, nw_n);
         // octet k-1: behind its field reads came 2 header reads and NDATA field reads
