@@ -616,7 +616,20 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         issue_loads(nxt);
         d_next = load_desc(s_next + nxt.n);
         // ---- walk + decode the current chunk ----------------------------------------------------------------------
-        if (cur.n != 0 && sa._pad != 1) {
+        const bool has_octets = cur.kind == K_NP || cur.kind == K_DELTA || cur.kind == K_XOR || cur.kind == K_RAW;
+        if ((MODE == MODE_FILTER || MODE == MODE_FILTER_BITS) && cur.n != 0 && __ballot(has_octets) == 0) {
+            // A chunk of Null / Const sections only (sparse vectors): no octet to walk, every section's
+            // count follows from its kind (src/filter.rs:222-223, :104-106; a Const section is 256 copies
+            // of one value).
+            if (sec < cur.n && (lane & 3) == 0) {
+                uint32_t r = res_pack(0, 0); // K_SKIP
+                if (cur.kind == K_NULL) r = res_pack(pa.match_zero ? FIXED_LEN : 0, 0);
+                else if (cur.kind == K_CONST)
+                    r = res_pack(pred_match<ETYPE, SINGLE>(pa, lds_load_unaligned<W>(lds_base + cur.rel + 1u)) ? FIXED_LEN : 0, 0);
+                else if (cur.kind == K_ILLEGAL) r = res_pack(0, CVEC_INVALID_FORMAT);
+                sec_res[s_cur + sec] = r;
+            }
+        } else if (cur.n != 0 && sa._pad != 1) {
             const bool odd = process_chunk<ETYPE, MODE, SINGLE, false>(data, lds_base, cur.kind, cur.rel, cur.len,
                                                                        sec < cur.n, s_cur + sec, lane, pa, sa, sec_res,
                                                                        masks, out_);
