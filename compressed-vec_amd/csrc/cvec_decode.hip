@@ -783,7 +783,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         const bool single = pa.count == 1;
         static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
         SinkArgs sa2 = sa;
-        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage the bytes but skip the octet loop
+        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage the bytes but skip the octet loop, 5 = loop without HBM traffic
 #define CVEC_LAUNCH_SEC(M, S)                                                                                       \
     k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
         if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);

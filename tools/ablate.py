@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times k_sections (HIP events inside the library) on the f32 filter workload; used with the
-CVEC_ABLATE / CVEC_SEC_THREADS debug knobs to price the phases of the kernel."""
+CVEC_ABLATE / CVEC_WG_ROUNDS / CVEC_WG_PER_CU debug knobs to price the phases of the kernel."""
 import ctypes as C
 import os
 import sys
@@ -27,5 +27,5 @@ ms = [C.c_float(0) for _ in range(3)]
 n = C.c_int32(0)
 lib.cvec_timing_end(C.byref(ms[0]), C.byref(ms[1]), C.byref(ms[2]), C.byref(n))
 print("ablate=%s threads=%s  k_index %.4f  k_sections %.4f  k_finalize %.4f ms" % (
-    os.environ.get("CVEC_ABLATE", "0"), os.environ.get("CVEC_SEC_THREADS", "default"),
+    os.environ.get("CVEC_ABLATE", "0"), os.environ.get("CVEC_WG_PER_CU", "default"),
     ms[0].value / n.value, ms[1].value / n.value, ms[2].value / n.value))
