@@ -434,6 +434,26 @@ def test_legacy_stream_codecs_vs_oracle(cv, oracle):
     assert list(cv.stream.unpack_u64_delta(enc, 12)) == [0, 1000, 1001, 1002, 1003, 2005, 2010, 3034, 4045, 5056, 6067, 7078]
 
 
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_large_ragged_batch_vs_oracle(cv, oracle, tname):
+    """Tens of thousands of sections: every wave of the section kernel runs many chunks, chunk boundaries
+    fall everywhere in the vectors, and 64-bit worst-case sections force short chunks."""
+    rng = np.random.default_rng(4000 + ET[tname])
+    vals, eo = _random_vectors(rng, tname, 5000, max_len=3000)
+    blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+    got = cv.encode_batch(tname, vals, eo)
+    assert np.array_equal(got.byte_off, bo) and np.array_equal(got.blob, blob)
+    dev = got.to_device()
+    dec, out_off = dev.decode()
+    want, st, rc = oracle.batch_decode(ET[tname], blob, bo, out_off)
+    assert rc == 0 and np.array_equal(_bits(dec), _bits(want))
+    nz = vals[vals != 0]
+    for p in (0, nz[7], [nz[1], nz[2], 0]):
+        total, per = dev.filter_count(p, per_vector=True)
+        wtotal, wper, wst, rc = oracle.batch_filter_count(ET[tname], blob, bo, p)
+        assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
