@@ -244,6 +244,7 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
     cvec_status st = check_view(batch);
     if (st) return st;
     if (!d_result || !d_workspace || (batch->n_sections && !d_out)) return CVEC_ERR_BAD_ARGUMENT;
+    if (((uintptr_t)d_out & 15) != 0) return CVEC_ERR_BAD_ARGUMENT; // the kernel stores 8 / 16 bytes per lane
     ReadWs w = carve_read_ws(d_workspace, batch->n_vectors, batch->n_sections);
     if (w.total > workspace_bytes) return CVEC_ERR_WORKSPACE;
     PredArgs pa;

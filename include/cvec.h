@@ -135,8 +135,8 @@ cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred
                                   void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of the batch.
- * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out holds 256 * n_sections
- * elements of the batch's type (layout: see cvec_dbatch_view). */
+ * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out (16-byte aligned) holds
+ * 256 * n_sections elements of the batch's type (layout: see cvec_dbatch_view). */
 cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
                             uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
                             void *stream);
