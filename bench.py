@@ -5,8 +5,9 @@
 
 One "step" = one fused decode+filter+count pass (reader.filter_iter(EqualsSink(3.0)) + count_hits,
 benches/bench.rs:238-241 of the reference) over the rank's whole batch, which is already resident in
-HBM; for N > 1 every rank owns its own shard of vectors (no data exchange) and the step ends with one
-RCCL all-reduce of the 8-byte match count.  Workload: 131072 vectors x 2048 f32 per GPU (1 GiB of
+HBM; for N > 1 every rank owns its own shard of vectors (no data exchange) and every step all-reduces
+its 8-byte match count over RCCL (asynchronously: the collective of a step overlaps the kernels of the
+next ones; all of them are complete before the clock stops).  Workload: 131072 vectors x 2048 f32 per GPU (1 GiB of
 uncompressed values per GPU; at N = 8 this is BASELINE.json's config 5: 1 Mi vectors of 2048).
 Rank 0 prints one JSON line; `value` is whole-job GB/s counted in uncompressed bytes."""
 import argparse
@@ -37,6 +38,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the encode / decode / PCIe side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-single", action="store_true",
+                    help="take the multi-rank code path (process group, all-reduce) with a single rank; for testing")
     return ap.parse_args()
 
 
@@ -79,7 +82,13 @@ def main():
               file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.dist_single
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import compressed_vec_amd as cv
@@ -117,33 +126,56 @@ def main():
     want_timed = int((values == PRED).sum().item())
 
     pred = cv.make_pred(cv.F32, PRED)
-    result = batch.result_buffer()
+    # Every step all-reduces its own count (RCCL).  The collective of step i runs on RCCL's stream beside
+    # the kernels of the following steps: a ring of result blocks keeps a step from overwriting a count
+    # that is still being reduced, and a block is reused only after its reduction has been waited for
+    # (a stream-side wait, the host does not block).
+    RING = 4
+    results = [torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device="cuda") for _ in range(RING)]
+    pending = [None] * RING
+    state = {"i": 0}
 
     def step():
-        batch.filter_count_async(pred, result=result)
-        if world > 1:
-            dist.all_reduce(result[:1], op=dist.ReduceOp.SUM)
+        j = state["i"] % RING
+        state["i"] += 1
+        if pending[j] is not None:
+            pending[j].wait()
+            pending[j] = None
+        batch.filter_count_async(pred, result=results[j])
+        if use_dist:
+            pending[j] = dist.all_reduce(results[j][:1], op=dist.ReduceOp.SUM, async_op=True)
+        return j
+
+    def drain():
+        for j in range(RING):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     N.check(lib.cvec_timing_begin(args.steps))
     t0 = time.perf_counter()
+    last = 0
     for _ in range(args.steps):
-        step()
+        last = step()
+    drain()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    result = results[last]
     ms = [C.c_float(0), C.c_float(0), C.c_float(0)]
     nrec = C.c_int32(0)
     N.check(lib.cvec_timing_end(C.byref(ms[0]), C.byref(ms[1]), C.byref(ms[2]), C.byref(nrec)))
     total_count = int(result[0].item())
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -201,7 +233,7 @@ def main():
             out["extra"] = side_measurements(torch, cv, batch, values, elem_off, raw_bytes)
             out["extra"]["first_encode_call_s"] = round(t_first_encode, 4)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
