@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the encode / decode / PCIe side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "1")),
+                    help="independent steps in flight: step i runs on stream i %% streams with its own workspace")
     ap.add_argument("--dist-single", action="store_true",
                     help="take the multi-rank code path (process group, all-reduce) with a single rank; for testing")
     return ap.parse_args()
@@ -134,16 +136,27 @@ def main():
     results = [torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device="cuda") for _ in range(RING)]
     pending = [None] * RING
     state = {"i": 0}
+    # --streams S > 1: consecutive steps are independent queries over the same resident batch; step i is
+    # enqueued on stream i % S with a workspace of its own, so the short index / finalize kernels of one
+    # step run beside the section kernel of another.
+    nstreams = max(1, args.streams)
+    views = [batch] + [cv.DeviceBatch(batch.etype, batch.d_bytes, batch.d_byte_off, batch.d_sec_base, batch.n_vectors,
+                                      batch.n_sections, batch.n_bytes) for _ in range(nstreams - 1)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
+    for st in streams[1:]:
+        st.wait_stream(streams[0])
 
     def step():
-        j = state["i"] % RING
+        i = state["i"]
+        j = i % RING
         state["i"] += 1
-        if pending[j] is not None:
-            pending[j].wait()
-            pending[j] = None
-        batch.filter_count_async(pred, result=results[j])
-        if use_dist:
-            pending[j] = dist.all_reduce(results[j][:1], op=dist.ReduceOp.SUM, async_op=True)
+        with torch.cuda.stream(streams[i % nstreams]):
+            if pending[j] is not None:
+                pending[j].wait()
+                pending[j] = None
+            views[i % nstreams].filter_count_async(pred, result=results[j])
+            if use_dist:
+                pending[j] = dist.all_reduce(results[j][:1], op=dist.ReduceOp.SUM, async_op=True)
         return j
 
     def drain():
@@ -206,6 +219,7 @@ def main():
                                "filter == %.1f + count_hits%s" % (nvec, VEC_LEN, PRED,
                                                                   ", RCCL all-reduce of the count" if world > 1 else ""),
                    "vectors_per_gpu": nvec, "vector_len": VEC_LEN, "parallelism": "shard%d" % world,
+                   "steps_in_flight": nstreams,
                    "compressed_bytes_per_gpu": batch.n_bytes,
                    "compressed_bytes_per_element": round(batch.n_bytes / n_elems, 4)},
     }
