@@ -195,13 +195,24 @@ template <class U> __device__ inline OctInfo octet_info(U y, int lane) {
     return o;
 }
 
+// Values of one section through a buffer descriptor that ends after the `valid` existing elements:
+// lanes beyond it read 0 without a branch and without traffic (finish() pads the last section with
+// zeros, src/vector.rs:352-355), and valid == 0 is a harmless no-op load.  Branch-free loads let the
+// compiler count them, so the loads of the next section stay in flight under the work on this one.
 template <int ETYPE>
 __device__ inline void load_section(const typename EncT<ETYPE>::U *__restrict__ values, uint64_t e0, uint32_t valid,
                                     int lane, typename EncT<ETYPE>::U x[4]) {
+    constexpr int W = EncT<ETYPE>::W;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(values + e0), 0, (int)(valid * W), 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint32_t e = 64 * i + lane;
-        x[i] = e < valid ? values[e0 + e] : 0; // finish() pads the last section with zeros (src/vector.rs:352-355)
+        if constexpr (W == 4) {
+            x[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, i * 256, 0);
+        } else {
+            typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, i * 512, 0);
+            x[i] = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+        }
     }
 }
 
@@ -218,38 +229,76 @@ __global__ void k_enc_map(const uint64_t *__restrict__ sec_base, uint64_t n, uin
     for (uint64_t s = sec_base[v]; s < sec_base[v + 1]; s++) sec_vec[s] = (uint32_t)v;
 }
 
+// ---- runs of sections ---------------------------------------------------------------------------------
+// A wave encodes a run of `run` consecutive section slots.  Lane l looks up where slot0 + l lives
+// (three dependent loads, paid once per run instead of once per section); the loop reads the
+// description of section r with readlane and loads the values of section r + 1 before it works on
+// section r, so every wave keeps two sections of loads in flight.
+constexpr int ENC_MAX_RUN = 16;
+
+struct RunMeta {
+    uint64_t e0;    // first element of the section in `values`
+    uint32_t valid; // elements that exist (the rest of the section is zero padding); 0 = no section
+};
+
+__device__ inline RunMeta run_meta(const uint64_t *__restrict__ elem_off, const uint64_t *__restrict__ sec_base,
+                                   const uint32_t *__restrict__ sec_vec, uint64_t n_slots, uint64_t slot, bool active) {
+    RunMeta m;
+    m.e0 = 0; m.valid = 0;
+    if (active && slot < n_slots) {
+        const uint32_t v = sec_vec[slot];
+        const uint64_t k = slot - sec_base[v];
+        m.e0 = elem_off[v] + k * FIXED_LEN;
+        const uint64_t left = elem_off[v + 1] - m.e0;
+        m.valid = (uint32_t)(left < FIXED_LEN ? left : FIXED_LEN);
+    }
+    return m;
+}
+__device__ inline uint32_t lane_val(uint32_t x, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)x, r); }
+__device__ inline uint64_t lane_val(uint64_t x, int r) {
+    return (uint64_t)lane_val((uint32_t)x, r) | ((uint64_t)lane_val((uint32_t)(x >> 32), r) << 32);
+}
+__device__ inline uint64_t wave_slot0(uint32_t run) {
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    return ((uint64_t)blockIdx.x * (ENC_THREADS / 64) + w) * run;
+}
+
 // ---- pass A: section sizes ------------------------------------------------------------------------
 template <int ETYPE>
 __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const typename EncT<ETYPE>::U *__restrict__ values,
                                                             const uint64_t *__restrict__ elem_off,
                                                             const uint64_t *__restrict__ sec_base, uint64_t n_vectors,
                                                             const uint32_t *__restrict__ sec_vec, uint64_t max_slots,
-                                                            uint64_t *__restrict__ sec_size) {
+                                                            uint32_t run, uint64_t *__restrict__ sec_size) {
     using U = typename EncT<ETYPE>::U;
     constexpr int W = EncT<ETYPE>::W;
     const int lane = threadIdx.x & 63;
-    const uint64_t slot = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + (threadIdx.x >> 6);
-    if (slot >= max_slots) return;
-    const uint64_t n_slots = sec_base[n_vectors];
-    if (slot >= n_slots) { if (lane == 0) sec_size[slot] = 0; return; }
-    const uint32_t v = sec_vec[slot];
-    const uint64_t k = slot - sec_base[v];
-    const uint64_t e0 = elem_off[v] + k * FIXED_LEN, eend = elem_off[v + 1];
-    const uint32_t valid = (uint32_t)((eend - e0) < FIXED_LEN ? (eend - e0) : FIXED_LEN);
-    U x[4];
-    load_section<ETYPE>(values, e0, valid, lane, x);
-    const SecPlan<U> p = plan_section<ETYPE>(x, lane);
-    uint32_t size;
-    if (p.kind == K_NULL) size = 1;
-    else if (p.kind == K_CONST) size = 1 + W;
-    else {
-        transform_section<ETYPE>(x, p.kind, p.minv, lane);
-        uint32_t s = 0;
+    const uint64_t slot0 = wave_slot0(run);
+    if (slot0 >= max_slots) return;
+    const uint64_t slot = slot0 + lane;
+    const RunMeta m = run_meta(elem_off, sec_base, sec_vec, sec_base[n_vectors], slot, (uint32_t)lane < run);
+    const int cnt = __popcll(__ballot(m.valid != 0));
+    uint32_t my_size = 0; // slots past the last section get size 0
+    U xa[4], xn[4];
+    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane, xa);
+    for (int r = 0; r < cnt; r++) {
+        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane, xn); // lane cnt: valid = 0
+        const SecPlan<U> p = plan_section<ETYPE>(xa, lane);
+        uint32_t size;
+        if (p.kind == K_NULL) size = 1;
+        else if (p.kind == K_CONST) size = 1 + W;
+        else {
+            transform_section<ETYPE>(xa, p.kind, p.minv, lane);
+            uint32_t s = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) s += octet_info<U>(x[i], lane).size; // every lane of a group holds its octet's size
-        size = (p.kind == K_DELTA ? DELTA_HDR : 3) + group_scan_total(s).total;
+            for (int i = 0; i < 4; i++) s += octet_info<U>(xa[i], lane).size; // every lane of a group holds its octet's size
+            size = (p.kind == K_DELTA ? DELTA_HDR : 3) + group_scan_total(s).total;
+        }
+        if (lane == r) my_size = size;
+#pragma unroll
+        for (int i = 0; i < 4; i++) xa[i] = xn[i];
     }
-    if (lane == 0) sec_size[slot] = size;
+    if ((uint32_t)lane < run && slot < max_slots) sec_size[slot] = my_size;
 }
 
 // ---- headers + byte_off -----------------------------------------------------------------------------
@@ -329,18 +378,23 @@ __device__ inline void image_octets(const U x[4], int lane, uint32_t *buf, uint3
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
-// Whole 16-byte pieces as aligned dwordx4, the partial first / last piece byte by byte.
+// Whole 16-byte pieces as aligned dwordx4 by all lanes; the partial first and last piece one byte per
+// lane (lanes 0..15 the first, 16..31 the last), so no lane loops over bytes.
 __device__ inline void image_copy_out(const uint32_t *buf, uint32_t phase, uint32_t size, uint8_t *dst, int lane) {
     const uint8_t *img = (const uint8_t *)buf;
     uint8_t *gdst = dst - phase; // 16-byte aligned
-    const uint32_t npieces = (phase + size + 15) >> 4;
+    const uint32_t end = phase + size;
+    const uint32_t npieces = (end + 15) >> 4;
     for (uint32_t d = lane; d < npieces; d += 64) {
-        const uint32_t lo = 16 * d, hi = lo + 16;
-        if (lo >= phase && hi <= phase + size) {
-            *(uint4 *)(gdst + lo) = ((const uint4 *)buf)[d];
-        } else {
-            const uint32_t b0 = lo > phase ? lo : phase, b1 = hi < phase + size ? hi : phase + size;
-            for (uint32_t b = b0; b < b1; b++) gdst[b] = img[b];
+        const uint32_t lo = 16 * d;
+        if (lo >= phase && lo + 16 <= end) *(uint4 *)(gdst + lo) = ((const uint4 *)buf)[d];
+    }
+    if (lane < 32) {
+        const bool last = lane >= 16;
+        if (!last || npieces > 1) {
+            const uint32_t b = 16 * (last ? npieces - 1 : 0u) + (lane & 15);
+            const bool full = last ? (end & 15) == 0 : (phase == 0 && end >= 16);
+            if (!full && b >= phase && b < end) gdst[b] = img[b];
         }
     }
 }
@@ -353,57 +407,66 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
                                                            const uint64_t *__restrict__ elem_off,
                                                            const uint64_t *__restrict__ sec_base, uint64_t n_vectors,
                                                            const uint32_t *__restrict__ sec_vec, uint64_t max_slots,
-                                                           const uint64_t *__restrict__ sec_scan,
+                                                           uint32_t run, const uint64_t *__restrict__ sec_scan,
                                                            uint8_t *__restrict__ bytes) {
     using U = typename EncT<ETYPE>::U;
     constexpr int W = EncT<ETYPE>::W;
     __shared__ __attribute__((aligned(16))) uint32_t s_buf[ENC_THREADS / 64][EncBuf<W>::DWORDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t slot = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + wave;
-    if (slot >= max_slots) return;
-    if (slot >= sec_base[n_vectors]) return;
-    const uint32_t v = sec_vec[slot];
-    const uint64_t k = slot - sec_base[v];
-    const uint64_t e0 = elem_off[v] + k * FIXED_LEN, eend = elem_off[v + 1];
-    const uint32_t valid = (uint32_t)((eend - e0) < FIXED_LEN ? (eend - e0) : FIXED_LEN);
-    const uint64_t dst_off = HEADER_BYTES * ((uint64_t)v + 1) + sec_scan[slot];
-    const uint32_t size = (uint32_t)(sec_scan[slot + 1] - sec_scan[slot]);
-    uint8_t *dst = bytes + dst_off;
-
-    U x[4];
-    load_section<ETYPE>(values, e0, valid, lane, x);
-    const SecPlan<U> p = plan_section<ETYPE>(x, lane);
-    if (p.kind == K_NULL) { // NullFixedSect::write (src/section.rs:440-443)
-        if (lane == 0) dst[0] = (uint8_t)K_NULL;
-        return;
+    const int lane = threadIdx.x & 63;
+    uint32_t *buf = s_buf[threadIdx.x >> 6];
+    const uint64_t slot0 = wave_slot0(run);
+    if (slot0 >= max_slots) return;
+    const uint64_t slot = slot0 + lane;
+    const RunMeta m = run_meta(elem_off, sec_base, sec_vec, sec_base[n_vectors], slot, (uint32_t)lane < run);
+    uint64_t m_dst = 0;
+    uint32_t m_size = 0;
+    if (m.valid) {
+        const uint64_t at = sec_scan[slot];
+        m_dst = HEADER_BYTES * ((uint64_t)sec_vec[slot] + 1) + at;
+        m_size = (uint32_t)(sec_scan[slot + 1] - at);
     }
-    if (p.kind == K_CONST) { // ConstFixedSect::write (src/section.rs:795-803): values[0], not min
-        if (lane == 0) {
-            dst[0] = (uint8_t)K_CONST;
-            if constexpr (W == 4) *(u32u *)(dst + 1) = p.first; else *(u64u *)(dst + 1) = p.first;
+    const int cnt = __popcll(__ballot(m.valid != 0));
+    U x[4], xn[4];
+    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane, x);
+    for (int r = 0; r < cnt; r++) {
+        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane, xn); // lane cnt: valid = 0
+        const uint64_t dst_off = lane_val(m_dst, r);
+        const uint32_t size = lane_val(m_size, r);
+        uint8_t *dst = bytes + dst_off;
+        const SecPlan<U> p = plan_section<ETYPE>(x, lane);
+        if (p.kind == K_NULL) { // NullFixedSect::write (src/section.rs:440-443)
+            if (lane == 0) dst[0] = (uint8_t)K_NULL;
+        } else if (p.kind == K_CONST) { // ConstFixedSect::write (src/section.rs:795-803): values[0], not min
+            if (lane == 0) {
+                dst[0] = (uint8_t)K_CONST;
+                if constexpr (W == 4) *(u32u *)(dst + 1) = p.first; else *(u64u *)(dst + 1) = p.first;
+            }
+        } else {
+            const uint32_t phase = (uint32_t)(dst_off & 15);   // bytes is 16-byte aligned: the phase of dst itself
+            uint8_t *bufb = (uint8_t *)buf + phase;            // section byte 0
+            const uint32_t npieces = (phase + size + 15) >> 4; // 16-byte pieces of the image
+            // the copy-out reads of the previous section of this wave were issued before these writes
+            // and LDS serves one wave in order
+            for (uint32_t d = lane; d < npieces; d += 64) ((uint4 *)buf)[d] = make_uint4(0, 0, 0, 0);
+            const uint32_t hdr = p.kind == K_DELTA ? DELTA_HDR : 3;
+            if (lane == 0) {
+                bufb[0] = (uint8_t)p.kind;
+                // NP / Delta: bytes after the header; Xor: total including the 3 header bytes
+                // (src/section.rs:579-581, :659-661, :745-748)
+                const uint32_t len16 = p.kind == K_XOR ? size : size - hdr;
+                bufb[1] = (uint8_t)len16; bufb[2] = (uint8_t)(len16 >> 8);
+                if (p.kind == K_DELTA) {
+                    bufb[3] = (uint8_t)bitlen_u((U)(p.maxv - p.minv));          // src/section.rs:663
+                    for (int i = 0; i < W; i++) bufb[4 + i] = (uint8_t)(p.minv >> (8 * i)); // base; bytes 4+W..11 stay 0
+                }
+            }
+            transform_section<ETYPE>(x, p.kind, p.minv, lane);
+            image_octets<U>(x, lane, buf, phase, hdr, 32);
+            image_copy_out(buf, phase, size, dst, lane);
         }
-        return;
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[i] = xn[i];
     }
-    uint32_t *buf = s_buf[wave];
-    const uint32_t phase = (uint32_t)(dst_off & 15);   // bytes is 16-byte aligned: the phase of dst itself
-    uint8_t *bufb = (uint8_t *)buf + phase;            // section byte 0
-    const uint32_t npieces = (phase + size + 15) >> 4; // 16-byte pieces of the image
-    for (uint32_t d = lane; d < npieces; d += 64) ((uint4 *)buf)[d] = make_uint4(0, 0, 0, 0);
-    const uint32_t hdr = p.kind == K_DELTA ? DELTA_HDR : 3;
-    if (lane == 0) {
-        bufb[0] = (uint8_t)p.kind;
-        // NP / Delta: bytes after the header; Xor: total including the 3 header bytes
-        // (src/section.rs:579-581, :659-661, :745-748)
-        const uint32_t len16 = p.kind == K_XOR ? size : size - hdr;
-        bufb[1] = (uint8_t)len16; bufb[2] = (uint8_t)(len16 >> 8);
-        if (p.kind == K_DELTA) {
-            bufb[3] = (uint8_t)bitlen_u((U)(p.maxv - p.minv));          // src/section.rs:663
-            for (int i = 0; i < W; i++) bufb[4 + i] = (uint8_t)(p.minv >> (8 * i)); // base; bytes 4+W..11 stay 0
-        }
-    }
-    transform_section<ETYPE>(x, p.kind, p.minv, lane);
-    image_octets<U>(x, lane, buf, phase, hdr, 32);
-    image_copy_out(buf, phase, size, dst, lane);
 }
 
 // ---- legacy stream codecs: pack_u64_delta / pack_f64_xor (reference src/nibblepacking.rs:15-45) ----
@@ -623,14 +686,18 @@ static void launch_encode_t(const void *d_values, const uint64_t *d_elem_off, ui
     (void)launch_exclusive_scan(d_sec_base, n, d_sec_base, w.scan_scratch, stream);
     if (max_slots > 0) {
         k_enc_map<<<vblocks, 256, 0, stream>>>(d_sec_base, n, w.sec_vec);
-        const uint32_t sblocks = (uint32_t)((max_slots + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
+        // sections per wave: long runs amortise the slot lookup, but the chip wants >= 16 Ki waves
+        uint32_t run = (uint32_t)(max_slots / 16384);
+        run = run < 1 ? 1 : run > (uint32_t)ENC_MAX_RUN ? (uint32_t)ENC_MAX_RUN : run;
+        const uint64_t waves = (max_slots + run - 1) / run;
+        const uint32_t sblocks = (uint32_t)((waves + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
         k_enc_sizes<ETYPE><<<sblocks, ENC_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
-                                                                max_slots, w.sec_size);
+                                                                max_slots, run, w.sec_size);
         (void)launch_exclusive_scan(w.sec_size, max_slots, w.sec_scan, w.scan_scratch, stream);
         k_enc_headers<<<vblocks, 256, 0, stream>>>(ETYPE, d_elem_off, d_sec_base, w.sec_scan, n, d_bytes, d_byte_off,
                                                    d_result);
         k_enc_emit<ETYPE><<<sblocks, ENC_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
-                                                               max_slots, w.sec_scan, d_bytes);
+                                                               max_slots, run, w.sec_scan, d_bytes);
     } else {
         (void)hipMemsetAsync(w.sec_scan, 0, 16, stream);
         k_enc_headers<<<vblocks, 256, 0, stream>>>(ETYPE, d_elem_off, d_sec_base, w.sec_scan, n, d_bytes, d_byte_off,
