@@ -1,13 +1,13 @@
 // cvec_encode.hip — gfx950 kernels for the write side: Vector{U32,U64,F32Xor}Appender::encode_all
 // (reference src/vector.rs:238-246) for a batch of vectors.
 //
-// One wavefront encodes one 256-element section.  Lane L holds elements L, L+64, L+128, L+192, so
-// register i of lanes 8g..8g+7 is octet 8i+g and the octet-level quantities of NibblePack
-// (reference src/nibblepacking.rs:108-153) are 8-lane group operations:
-//   nonzero bitmask      = one byte of a wave ballot
-//   nibble word          = clz/ctz of the OR over the 8 lanes (xor-butterfly over lanes 1, 2, 4)
-//   octet byte offsets   = exclusive scan of the 32 octet sizes (lane strides 8, 16, 32 + carry)
-//   bitstream            = every nonzero lane ORs its field into a zeroed LDS image of the section
+// One wavefront encodes one 256-element section at a time.  Lane L holds elements 4L..4L+3, so the
+// lane pair (2o, 2o+1) holds octet o and the octet-level quantities of NibblePack (reference
+// src/nibblepacking.rs:108-153) are computed once per section for all 32 octets:
+//   nonzero bitmask      = the lane's four nonzero bits joined with its partner's (one DPP swap)
+//   nibble word          = clz/ctz of the OR of the lane's values and its partner's
+//   octet byte offsets   = wavefront scan of the 32 octet sizes (DPP row shifts + row broadcasts)
+//   bitstream            = every lane ORs its (adjacent) fields into a zeroed LDS image of the section
 // Because a section's byte offset depends on every section before it, the work is two passes over
 // the values: sizes → exclusive scan of section sizes → emit.
 #include "cvec_device.hpp"
@@ -39,11 +39,17 @@ template <int CTRL, int ROW_MASK, bool BOUND> __device__ inline float dpp_mov(fl
     return __uint_as_float(dpp_mov<CTRL, ROW_MASK, BOUND>(__float_as_uint(old), __float_as_uint(v)));
 }
 constexpr int DPP_QUAD_1032 = 0xb1, DPP_QUAD_2301 = 0x4e, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
-              DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+              DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
 __device__ inline uint32_t lane63(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
 __device__ inline uint64_t lane63(uint64_t x) { return (uint64_t)lane63((uint32_t)x) | ((uint64_t)lane63((uint32_t)(x >> 32)) << 32); }
 __device__ inline float lane63(float x) { return __uint_as_float(lane63(__float_as_uint(x))); }
+
+// Value of lane r (uniform r), the same in every lane.
+__device__ inline uint32_t lane_val(uint32_t x, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)x, r); }
+__device__ inline uint64_t lane_val(uint64_t x, int r) {
+    return (uint64_t)lane_val((uint32_t)x, r) | ((uint64_t)lane_val((uint32_t)(x >> 32), r) << 32);
+}
 
 // Wave-wide reduction with an idempotent-safe combine (min / max / or: combining a lane with itself
 // is harmless, which the masked row broadcasts rely on); the result is uniform (read from lane 63).
@@ -87,22 +93,25 @@ template <int ETYPE>
 __device__ inline SecPlan<typename EncT<ETYPE>::U> plan_section(const typename EncT<ETYPE>::U x[4], int lane) {
     using U = typename EncT<ETYPE>::U;
     SecPlan<U> p;
-    p.first = __shfl(x[0], 0, 64);
+    p.first = lane_val(x[0], 0);
     if constexpr (ETYPE == CVEC_F32) {
         float f[4];
-        unsigned long long nanb[4];
+        uint32_t nan4 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { f[i] = __uint_as_float(x[i]); nanb[i] = __ballot(f[i] != f[i]); }
+        for (int i = 0; i < 4; i++) { f[i] = __uint_as_float(x[i]); nan4 |= (uint32_t)(f[i] != f[i]) << i; }
         int q = -1; // index of the last NaN
-#pragma unroll
-        for (int i = 0; i < 4; i++) if (nanb[i]) q = 64 * i + 63 - __builtin_clzll(nanb[i]);
+        const unsigned long long nanb = __ballot(nan4 != 0);
+        if (nanb) {
+            const int lq = 63 - __builtin_clzll(nanb);
+            q = 4 * lq + 31 - __clz((int)__builtin_amdgcn_readlane((int)nan4, lq));
+        }
         const float inf = __builtin_inff();
         float mn = inf, mx = -inf;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const bool isn = f[i] != f[i];
             mn = (!isn && f[i] < mn) ? f[i] : mn;
-            mx = (64 * i + lane > q && f[i] > mx) ? f[i] : mx;
+            mx = (4 * lane + i > q && f[i] > mx) ? f[i] : mx;
         }
         mn = wave_min_f(mn);
         mx = wave_max_f(mx);
@@ -137,13 +146,12 @@ __device__ inline void transform_section(typename EncT<ETYPE>::U x[4], uint32_t 
                                          typename EncT<ETYPE>::U minv, int lane) {
     using U = typename EncT<ETYPE>::U;
     if constexpr (ETYPE == CVEC_F32) {
-        // element e-8 sits 8 lanes below in the same register, or (lanes 0..7) in lanes 56..63 of the
-        // previous register: one lane rotation by 8 of a register that already holds the wrap values
+        // element e-8 is the same register two lanes down
         U prev[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const U src = lane >= 56 ? (i > 0 ? x[i > 0 ? i - 1 : 0] : (U)0) : x[i];
-            prev[i] = __shfl(src, (lane + 56) & 63, 64);
+            const U below = __shfl(x[i], (lane + 62) & 63, 64);
+            prev[i] = lane >= 2 ? below : (U)0;
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] ^= prev[i];
@@ -155,12 +163,15 @@ __device__ inline void transform_section(typename EncT<ETYPE>::U x[4], uint32_t 
     }
 }
 
-// Inclusive scan over the 8 octet groups of a wave (group g = lanes 8g..8g+7, all lanes of a group
-// holding the same value) and its total: stride 8 inside a 16-lane row, then row broadcasts.
-struct GroupScan { uint32_t incl, total; };
-__device__ inline GroupScan group_scan_total(uint32_t v) {
-    GroupScan r;
-    uint32_t x = v + dpp_mov<DPP_ROW_SHR8, 0xf, true>(0u, v);
+// Inclusive scan over the 32 octets of a wave (both lanes of pair o hold the value of octet o) and
+// its total.  With the odd lanes counted as 0, the first step of a lane-wise scan (shift by one)
+// reproduces the input, so the scan starts at shift two: row shifts, then row broadcasts.
+struct PairScan { uint32_t incl, total; };
+__device__ inline PairScan pair_scan_total(uint32_t v) {
+    PairScan r;
+    uint32_t x = v + dpp_mov<DPP_ROW_SHR2, 0xf, true>(0u, v);
+    x += dpp_mov<DPP_ROW_SHR4, 0xf, true>(0u, x);
+    x += dpp_mov<DPP_ROW_SHR8, 0xf, true>(0u, x);
     x += dpp_mov<DPP_ROW_BCAST15, 0xa, false>(0u, x);
     x += dpp_mov<DPP_ROW_BCAST31, 0xc, false>(0u, x);
     r.incl = x;
@@ -169,51 +180,56 @@ __device__ inline GroupScan group_scan_total(uint32_t v) {
 }
 
 struct OctInfo {
-    uint32_t mask;  // nonzero bitmask of this lane's octet
-    uint32_t n, t;  // nibbles kept, trailing zero nibbles dropped
-    uint32_t size;  // octet bytes
+    uint32_t mask;   // nonzero bitmask of this lane's octet
+    uint32_t m4;     // nonzero bits of this lane's four values
+    uint32_t n4, t4; // bits kept per value, trailing zero bits dropped (both multiples of 4)
+    uint32_t size;   // octet bytes
 };
 
-template <class U> __device__ inline OctInfo octet_info(U y, int lane) {
+template <class U> __device__ inline OctInfo octet_info(const U x[4], int lane) {
     OctInfo o;
-    const unsigned long long b = __ballot(y != 0);
-    o.mask = (uint32_t)(b >> (lane & 56)) & 0xffu;
-    U r = y;
+    U r = (x[0] | x[1]) | (x[2] | x[3]);
     r |= dpp_mov<DPP_QUAD_1032, 0xf, false>(r, r);
-    r |= dpp_mov<DPP_QUAD_2301, 0xf, false>(r, r);
-    r |= dpp_mov<DPP_ROW_HALF_MIRROR, 0xf, false>(r, r);
+    o.m4 = (uint32_t)(x[0] != 0) | (uint32_t)(x[1] != 0) << 1 | (uint32_t)(x[2] != 0) << 2 | (uint32_t)(x[3] != 0) << 3;
+    const uint32_t pm = dpp_mov<DPP_QUAD_1032, 0xf, false>(o.m4, o.m4);
+    o.mask = (lane & 1) ? (pm | o.m4 << 4) : (o.m4 | pm << 4);
     if (o.mask) {
         uint32_t lz, tz;
         if constexpr (sizeof(U) == 8) { lz = (uint32_t)__clzll((long long)r); tz = (uint32_t)__ffsll((long long)r) - 1; }
         else { lz = 32u + (uint32_t)__clz((int)r); tz = (uint32_t)__ffs((int)r) - 1; }
-        o.t = tz >> 2;
-        o.n = 16 - (lz >> 2) - o.t;
-        o.size = 2 + ((o.n * __popc(o.mask) + 1) >> 1);
+        const uint32_t t = tz >> 2, n = 16 - (lz >> 2) - t;
+        o.t4 = 4 * t;
+        o.n4 = 4 * n;
+        o.size = 2 + ((n * __popc(o.mask) + 1) >> 1);
     } else {
-        o.t = 0; o.n = 0; o.size = 1;
+        o.t4 = 0; o.n4 = 0; o.size = 1;
     }
     return o;
 }
 
-// Values of one section through a buffer descriptor that ends after the `valid` existing elements:
-// lanes beyond it read 0 without a branch and without traffic (finish() pads the last section with
-// zeros, src/vector.rs:352-355), and valid == 0 is a harmless no-op load.  Branch-free loads let the
-// compiler count them, so the loads of the next section stay in flight under the work on this one.
+// Values of one section through a buffer descriptor of `avail` elements (what is left of the value
+// array, at most one section): 16-byte loads without a branch, and avail == 0 is a harmless no-op
+// load.  Branch-free loads let the compiler count them, so the loads of the next section stay in
+// flight under the work on this one.  Elements past `valid` become the zero padding of finish()
+// (src/vector.rs:352-355).
 template <int ETYPE>
 __device__ inline void load_section(const typename EncT<ETYPE>::U *__restrict__ values, uint64_t e0, uint32_t valid,
-                                    int lane, typename EncT<ETYPE>::U x[4]) {
+                                    uint32_t avail, int lane, typename EncT<ETYPE>::U x[4]) {
     constexpr int W = EncT<ETYPE>::W;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(values + e0), 0, (int)(valid * W), 0x00020000);
+    typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(values + e0), 0, (int)(avail * W), 0x00020000);
+    if constexpr (W == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if constexpr (W == 4) {
-            x[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, i * 256, 0);
-        } else {
-            typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
-            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, i * 512, 0);
-            x[i] = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
-        }
+        for (int i = 0; i < 4; i++) x[i] = v[i];
+    } else {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, 16, 0);
+        x[0] = (uint64_t)a[0] | ((uint64_t)a[1] << 32); x[1] = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+        x[2] = (uint64_t)b[0] | ((uint64_t)b[1] << 32); x[3] = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = (uint32_t)(4 * lane + i) < valid ? x[i] : 0;
 }
 
 // ---- vector → section bookkeeping -------------------------------------------------------------
@@ -239,24 +255,24 @@ constexpr int ENC_MAX_RUN = 16;
 struct RunMeta {
     uint64_t e0;    // first element of the section in `values`
     uint32_t valid; // elements that exist (the rest of the section is zero padding); 0 = no section
+    uint32_t avail; // elements of the value array from e0 on, at most one section
 };
 
 __device__ inline RunMeta run_meta(const uint64_t *__restrict__ elem_off, const uint64_t *__restrict__ sec_base,
-                                   const uint32_t *__restrict__ sec_vec, uint64_t n_slots, uint64_t slot, bool active) {
+                                   const uint32_t *__restrict__ sec_vec, uint64_t n_vectors, uint64_t slot, bool active) {
     RunMeta m;
-    m.e0 = 0; m.valid = 0;
+    m.e0 = 0; m.valid = 0; m.avail = 0;
+    const uint64_t n_slots = sec_base[n_vectors], n_values = elem_off[n_vectors];
     if (active && slot < n_slots) {
         const uint32_t v = sec_vec[slot];
         const uint64_t k = slot - sec_base[v];
         m.e0 = elem_off[v] + k * FIXED_LEN;
         const uint64_t left = elem_off[v + 1] - m.e0;
         m.valid = (uint32_t)(left < FIXED_LEN ? left : FIXED_LEN);
+        const uint64_t room = n_values - m.e0;
+        m.avail = (uint32_t)(room < FIXED_LEN ? room : FIXED_LEN);
     }
     return m;
-}
-__device__ inline uint32_t lane_val(uint32_t x, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)x, r); }
-__device__ inline uint64_t lane_val(uint64_t x, int r) {
-    return (uint64_t)lane_val((uint32_t)x, r) | ((uint64_t)lane_val((uint32_t)(x >> 32), r) << 32);
 }
 __device__ inline uint64_t wave_slot0(uint32_t run) {
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -276,23 +292,20 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_sizes(const typename EncT<E
     const uint64_t slot0 = wave_slot0(run);
     if (slot0 >= max_slots) return;
     const uint64_t slot = slot0 + lane;
-    const RunMeta m = run_meta(elem_off, sec_base, sec_vec, sec_base[n_vectors], slot, (uint32_t)lane < run);
+    const RunMeta m = run_meta(elem_off, sec_base, sec_vec, n_vectors, slot, (uint32_t)lane < run);
     const int cnt = __popcll(__ballot(m.valid != 0));
     uint32_t my_size = 0; // slots past the last section get size 0
     U xa[4], xn[4];
-    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane, xa);
+    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane_val(m.avail, 0), lane, xa);
     for (int r = 0; r < cnt; r++) {
-        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane, xn); // lane cnt: valid = 0
+        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane_val(m.avail, r + 1), lane, xn); // lane cnt: nothing to load
         const SecPlan<U> p = plan_section<ETYPE>(xa, lane);
         uint32_t size;
         if (p.kind == K_NULL) size = 1;
         else if (p.kind == K_CONST) size = 1 + W;
         else {
             transform_section<ETYPE>(xa, p.kind, p.minv, lane);
-            uint32_t s = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) s += octet_info<U>(xa[i], lane).size; // every lane of a group holds its octet's size
-            size = (p.kind == K_DELTA ? DELTA_HDR : 3) + group_scan_total(s).total;
+            size = (p.kind == K_DELTA ? DELTA_HDR : 3) + pair_scan_total(octet_info<U>(xa, lane).size).total;
         }
         if (lane == r) my_size = size;
 #pragma unroll
@@ -332,49 +345,56 @@ __global__ void k_enc_headers(int32_t etype, const uint64_t *__restrict__ elem_o
 // phase as its destination, so that the copy-out is aligned 16-byte traffic on both sides (a
 // misaligned LDS read costs ~16x an aligned one on gfx950).
 
-// Octets 8i+g (register i, lane group g) with index < noct: header bytes by the group's first lane,
-// every nonzero lane ORs its field into the zeroed image.  `first` = byte offset of octet 0 in the
-// section; `phase` = position of section byte 0 in the image.
+// ORs `bits` into the image at bit position `bitpos`; words that receive nothing are ORed with 0,
+// which is cheaper than a divergent branch around an LDS instruction.  The image has 16 spare bytes
+// behind the largest section for the words this touches past the end.
+__device__ inline void image_or(uint32_t *buf, uint32_t bitpos, uint32_t bits) {
+    const uint32_t d = bitpos >> 5, sh = bitpos & 31;
+    const uint64_t w = (uint64_t)bits << sh;
+    atomicOr(&buf[d], (uint32_t)w);
+    atomicOr(&buf[d + 1], (uint32_t)(w >> 32));
+}
+__device__ inline void image_or(uint32_t *buf, uint32_t bitpos, uint64_t bits) {
+    const uint32_t d = bitpos >> 5, sh = bitpos & 31;
+    const uint64_t lo = bits << sh;
+    const uint32_t hi = (uint32_t)((bits >> 32) >> 1 >> (31 - sh));
+    atomicOr(&buf[d], (uint32_t)lo);
+    atomicOr(&buf[d + 1], (uint32_t)(lo >> 32));
+    atomicOr(&buf[d + 2], hi);
+}
+
+// Octets o = lane / 2 with o < noct: the even lane of a pair ORs the two header bytes, every lane ORs
+// its fields into the zeroed image.  `first` = byte offset of octet 0 in the section; `phase` =
+// position of section byte 0 in the image.  Values of octets >= noct must be zero.
 template <class U>
 __device__ inline void image_octets(const U x[4], int lane, uint32_t *buf, uint32_t phase, uint32_t first,
                                     uint32_t noct) {
     constexpr int W = sizeof(U);
-    uint8_t *bufb = (uint8_t *)buf + phase;
-    const uint32_t g = lane >> 3, j = lane & 7;
-    uint32_t carry = first;
+    const OctInfo o = octet_info<U>(x, lane);
+    const bool exists = (uint32_t)(lane >> 1) < noct, odd = lane & 1;
+    const uint32_t osize = exists ? o.size : 0u;
+    const PairScan ps = pair_scan_total(osize);
+    const uint32_t off = phase + first + ps.incl - osize; // image byte of the octet's mask byte
+    // mask byte, then ((n - 1) << 4) | t when any value is nonzero (n4 = 4n, t4 = 4t)
+    const uint32_t word = o.mask ? (((o.n4 - 4) << 2) | (o.t4 >> 2)) << 8 : 0u;
+    image_or(buf, off * 8, (!odd && exists) ? (o.mask | word) : 0u);
+    // the lane's nonzero values are neighbours in the bitstream: they follow the nonzero values of
+    // the even lane (odd lanes) or start the stream (even lanes)
+    const uint32_t bit0 = (off + 2) * 8 + (odd ? (uint32_t)__popc(o.mask & 0xfu) * o.n4 : 0u);
+    if constexpr (W == 4) {
+        // two values at a time: at most 64 bits, the second slides down when the first is zero
+        const uint32_t f0 = x[0] >> o.t4, f1 = x[1] >> o.t4, f2 = x[2] >> o.t4, f3 = x[3] >> o.t4;
+        const uint64_t c01 = (o.m4 & 1) ? (uint64_t)f0 | ((uint64_t)f1 << o.n4) : (uint64_t)f1;
+        const uint64_t c23 = (o.m4 & 4) ? (uint64_t)f2 | ((uint64_t)f3 << o.n4) : (uint64_t)f3;
+        image_or(buf, bit0, c01);
+        image_or(buf, bit0 + (uint32_t)__popc(o.m4 & 3u) * o.n4, c23);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const OctInfo o = octet_info<U>(x[i], lane);
-        const bool exists = 8u * i + g < noct;
-        const uint32_t osize = exists ? o.size : 0u;
-        // exclusive scan of the octet sizes of groups 0..7 of this register
-        const GroupScan gs = group_scan_total(osize);
-        const uint32_t off = carry + gs.incl - osize;
-        carry += gs.total;
-        if (j == 0 && exists) {
-            bufb[off] = (uint8_t)o.mask;
-            if (o.mask) bufb[off + 1] = (uint8_t)(((o.n - 1) << 4) | o.t);
-        }
-        if (x[i] != 0 && exists) {
-            const uint32_t idx = __popc(o.mask & ((1u << j) - 1u));
-            const uint32_t bitpos = (phase + off + 2) * 8 + idx * 4 * o.n;
-            const U field = x[i] >> (4 * o.t);
-            const uint32_t d = bitpos >> 5, sh = bitpos & 31;
-            if constexpr (W == 4) {
-                const uint64_t w = (uint64_t)field << sh;
-                atomicOr(&buf[d], (uint32_t)w);
-                if ((uint32_t)(w >> 32)) atomicOr(&buf[d + 1], (uint32_t)(w >> 32));
-            } else {
-                const uint64_t lo = field << sh;
-                const uint32_t hi = sh ? (uint32_t)(field >> (64 - sh)) : 0u;
-                atomicOr(&buf[d], (uint32_t)lo);
-                if ((uint32_t)(lo >> 32)) atomicOr(&buf[d + 1], (uint32_t)(lo >> 32));
-                if (hi) atomicOr(&buf[d + 2], hi);
-            }
-        }
+        for (int i = 0; i < 4; i++)
+            image_or(buf, bit0 + (uint32_t)__popc(o.m4 & ((1u << i) - 1u)) * o.n4, (uint64_t)(x[i] >> o.t4));
     }
-    // byte stores above and the atomic ORs are LDS operations of ONE wave: they complete in order,
-    // so the image is final here without a barrier.
+    // the ORs above are LDS operations of ONE wave: they complete in order, so the image is final
+    // for this wave's reads without a barrier.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
@@ -417,7 +437,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
     const uint64_t slot0 = wave_slot0(run);
     if (slot0 >= max_slots) return;
     const uint64_t slot = slot0 + lane;
-    const RunMeta m = run_meta(elem_off, sec_base, sec_vec, sec_base[n_vectors], slot, (uint32_t)lane < run);
+    const RunMeta m = run_meta(elem_off, sec_base, sec_vec, n_vectors, slot, (uint32_t)lane < run);
     uint64_t m_dst = 0;
     uint32_t m_size = 0;
     if (m.valid) {
@@ -427,9 +447,9 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
     }
     const int cnt = __popcll(__ballot(m.valid != 0));
     U x[4], xn[4];
-    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane, x);
+    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane_val(m.avail, 0), lane, x);
     for (int r = 0; r < cnt; r++) {
-        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane, xn); // lane cnt: valid = 0
+        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane_val(m.avail, r + 1), lane, xn); // lane cnt: nothing to load
         const uint64_t dst_off = lane_val(m_dst, r);
         const uint32_t size = lane_val(m_size, r);
         uint8_t *dst = bytes + dst_off;
@@ -479,7 +499,7 @@ __device__ inline void load_stream_block(const uint64_t *__restrict__ v, uint64_
                                          uint64_t x[4]) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint64_t idx = i0 + 64 * i + lane;
+        const uint64_t idx = i0 + 4 * lane + i;
         uint64_t y = 0;
         if (idx < npacked) {
             if (KIND == CVEC_STREAM_F64_XOR) {
@@ -521,13 +541,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_stream_sizes(const uint64_t *__
     const uint32_t noct = (uint32_t)(((npacked - i0 < FIXED_LEN ? npacked - i0 : FIXED_LEN) + 7) / 8);
     uint64_t x[4];
     load_stream_block<KIND>(values + elem_off[s], npacked, i0, lane, x);
-    uint32_t sz = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t o = octet_info<uint64_t>(x[i], lane).size;
-        sz += 8u * i + (lane >> 3) < noct ? o : 0u;
-    }
-    const uint32_t total = group_scan_total(sz).total;
+    const uint32_t sz = (uint32_t)(lane >> 1) < noct ? octet_info<uint64_t>(x, lane).size : 0u;
+    const uint32_t total = pair_scan_total(sz).total;
     if (lane == 0) blk_size[blk] = total;
 }
 
