@@ -68,11 +68,32 @@ template <class U> __device__ inline U wave_min_u(U x) {
 template <class U> __device__ inline U wave_max_u(U x) {
     return wave_reduce<U>(x, [](U a, U b) { return b > a ? b : a; });
 }
-__device__ inline float wave_min_f(float x) {
-    return wave_reduce<float>(x, [](float a, float b) { return b < a ? b : a; });
+
+// Minimum of `mn` and maximum of `mx` over the wave, both at once, with the lane exchange fused into
+// the min / max instruction (the compiler keeps a separate DPP move and a copy per step).  A VGPR
+// written by a VALU instruction may be read through DPP two wait states later: the two chains
+// alternate and an s_nop fills the second state.  Rows that a masked row broadcast does not write
+// keep their value.  For floats no NaN may come in.
+#define CVEC_MINMAX_STEP(OPMIN, OPMAX, CTRL)                                                                          \
+    OPMIN " %0, %0, %0 " CTRL " bank_mask:0xf\n\t" OPMAX " %1, %1, %1 " CTRL " bank_mask:0xf\n\ts_nop 0\n\t"
+#define CVEC_MINMAX_WAVE(OPMIN, OPMAX)                                                                                \
+    "s_nop 1\n\t" CVEC_MINMAX_STEP(OPMIN, OPMAX, "quad_perm:[1,0,3,2] row_mask:0xf")                                \
+        CVEC_MINMAX_STEP(OPMIN, OPMAX, "quad_perm:[2,3,0,1] row_mask:0xf")                                            \
+        CVEC_MINMAX_STEP(OPMIN, OPMAX, "row_half_mirror row_mask:0xf")                                                \
+        CVEC_MINMAX_STEP(OPMIN, OPMAX, "row_mirror row_mask:0xf")                                                     \
+        CVEC_MINMAX_STEP(OPMIN, OPMAX, "row_bcast:15 row_mask:0xa")                                                   \
+        CVEC_MINMAX_STEP(OPMIN, OPMAX, "row_bcast:31 row_mask:0xc") "s_nop 0"
+__device__ inline void wave_minmax(float &mn, float &mx) {
+    asm("; wave min/max f32\n\t" CVEC_MINMAX_WAVE("v_min_f32_dpp", "v_max_f32_dpp") : "+v"(mn), "+v"(mx));
+    mn = lane63(mn); mx = lane63(mx);
 }
-__device__ inline float wave_max_f(float x) {
-    return wave_reduce<float>(x, [](float a, float b) { return b > a ? b : a; });
+__device__ inline void wave_minmax(uint32_t &mn, uint32_t &mx) {
+    asm("; wave min/max u32\n\t" CVEC_MINMAX_WAVE("v_min_u32_dpp", "v_max_u32_dpp") : "+v"(mn), "+v"(mx));
+    mn = lane63(mn); mx = lane63(mx);
+}
+__device__ inline void wave_minmax(uint64_t &mn, uint64_t &mx) {
+    mn = wave_min_u<uint64_t>(mn);
+    mx = wave_max_u<uint64_t>(mx);
 }
 __device__ inline uint32_t bitlen_u(uint32_t x) { return x ? 32u - (uint32_t)__clz(x) : 0u; }
 __device__ inline uint32_t bitlen_u(uint64_t x) { return x ? 64u - (uint32_t)__clzll((long long)x) : 0u; }
@@ -96,25 +117,30 @@ __device__ inline SecPlan<typename EncT<ETYPE>::U> plan_section(const typename E
     p.first = lane_val(x[0], 0);
     if constexpr (ETYPE == CVEC_F32) {
         float f[4];
-        uint32_t nan4 = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { f[i] = __uint_as_float(x[i]); nan4 |= (uint32_t)(f[i] != f[i]) << i; }
+        for (int i = 0; i < 4; i++) f[i] = __uint_as_float(x[i]);
+        const float inf = __builtin_inff();
+        float mn, mx;
         int q = -1; // index of the last NaN
-        const unsigned long long nanb = __ballot(nan4 != 0);
-        if (nanb) {
+        const unsigned long long nanb = __ballot(__builtin_isunordered(f[0], f[1]) || __builtin_isunordered(f[2], f[3]));
+        if (nanb == 0) {
+            mn = __builtin_fminf(__builtin_fminf(f[0], f[1]), __builtin_fminf(f[2], f[3]));
+            mx = __builtin_fmaxf(__builtin_fmaxf(f[0], f[1]), __builtin_fmaxf(f[2], f[3]));
+        } else {
+            uint32_t nan4 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) nan4 |= (uint32_t)(f[i] != f[i]) << i;
             const int lq = 63 - __builtin_clzll(nanb);
             q = 4 * lq + 31 - __clz((int)__builtin_amdgcn_readlane((int)nan4, lq));
-        }
-        const float inf = __builtin_inff();
-        float mn = inf, mx = -inf;
+            mn = inf; mx = -inf;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool isn = f[i] != f[i];
-            mn = (!isn && f[i] < mn) ? f[i] : mn;
-            mx = (4 * lane + i > q && f[i] > mx) ? f[i] : mx;
+            for (int i = 0; i < 4; i++) {
+                mn = f[i] < mn ? f[i] : mn; // false for a NaN
+                mx = (4 * lane + i > q && f[i] > mx) ? f[i] : mx;
+            }
         }
-        mn = wave_min_f(mn);
-        mx = wave_max_f(mx);
+        // no NaN reaches the reductions, and which zero survives does not matter below
+        wave_minmax(mn, mx);
         const float first = __uint_as_float(p.first);
         if (first != first) mn = first;                  // min fold is stuck on a leading NaN
         if (q == FIXED_LEN - 1) mx = __builtin_nanf(""); // max fold ends on a trailing NaN
@@ -126,8 +152,7 @@ __device__ inline SecPlan<typename EncT<ETYPE>::U> plan_section(const typename E
         U mn = x[0], mx = x[0];
 #pragma unroll
         for (int i = 1; i < 4; i++) { mn = x[i] < mn ? x[i] : mn; mx = x[i] > mx ? x[i] : mx; }
-        mn = wave_min_u<U>(mn);
-        mx = wave_max_u<U>(mx);
+        wave_minmax(mn, mx);
         p.minv = mn;
         p.maxv = mx;
         if (mn == mx) p.kind = (mn == 0) ? K_NULL : K_CONST;
