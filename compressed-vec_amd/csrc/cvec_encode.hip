@@ -538,15 +538,6 @@ __device__ inline void load_stream_block(const uint64_t *__restrict__ v, uint64_
     }
 }
 
-__device__ inline uint64_t stream_of_block(const uint64_t *__restrict__ blk_base, uint64_t n, uint64_t blk) {
-    uint64_t lo = 0, hi = n; // last s with blk_base[s] <= blk
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (blk_base[mid] <= blk) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 __device__ inline uint64_t stream_packed_values(int kind, uint64_t n) {
     return kind == CVEC_STREAM_F64_XOR ? (n ? n - 1 : 0) : n;
 }
@@ -554,13 +545,14 @@ __device__ inline uint64_t stream_packed_values(int kind, uint64_t n) {
 template <int KIND>
 __global__ __launch_bounds__(ENC_THREADS) void k_stream_sizes(const uint64_t *__restrict__ values,
                                                                const uint64_t *__restrict__ elem_off,
-                                                               const uint64_t *__restrict__ blk_base, uint64_t n,
+                                                               const uint64_t *__restrict__ blk_base,
+                                                               const uint32_t *__restrict__ blk_stream, uint64_t n,
                                                                uint64_t max_blocks, uint64_t *__restrict__ blk_size) {
     const int lane = threadIdx.x & 63;
     const uint64_t blk = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + (threadIdx.x >> 6);
     if (blk >= max_blocks) return;
     if (blk >= blk_base[n]) { if (lane == 0) blk_size[blk] = 0; return; }
-    const uint64_t s = stream_of_block(blk_base, n, blk);
+    const uint64_t s = blk_stream[blk];
     const uint64_t npacked = stream_packed_values(KIND, elem_off[s + 1] - elem_off[s]);
     const uint64_t i0 = (blk - blk_base[s]) * FIXED_LEN;
     const uint32_t noct = (uint32_t)(((npacked - i0 < FIXED_LEN ? npacked - i0 : FIXED_LEN) + 7) / 8);
@@ -599,7 +591,8 @@ __global__ void k_stream_offsets(int kind, const uint64_t *__restrict__ values, 
 template <int KIND>
 __global__ __launch_bounds__(ENC_THREADS) void k_stream_emit(const uint64_t *__restrict__ values,
                                                               const uint64_t *__restrict__ elem_off,
-                                                              const uint64_t *__restrict__ blk_base, uint64_t n,
+                                                              const uint64_t *__restrict__ blk_base,
+                                                              const uint32_t *__restrict__ blk_stream, uint64_t n,
                                                               uint64_t max_blocks, const uint64_t *__restrict__ blk_scan,
                                                               const uint64_t *__restrict__ byte_off,
                                                               uint8_t *__restrict__ bytes) {
@@ -607,7 +600,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_stream_emit(const uint64_t *__r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t blk = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + wave;
     if (blk >= max_blocks || blk >= blk_base[n]) return;
-    const uint64_t s = stream_of_block(blk_base, n, blk);
+    const uint64_t s = blk_stream[blk];
     const uint64_t npacked = stream_packed_values(KIND, elem_off[s + 1] - elem_off[s]);
     const uint64_t i0 = (blk - blk_base[s]) * FIXED_LEN;
     const uint32_t noct = (uint32_t)(((npacked - i0 < FIXED_LEN ? npacked - i0 : FIXED_LEN) + 7) / 8);
@@ -625,6 +618,7 @@ __global__ __launch_bounds__(ENC_THREADS) void k_stream_emit(const uint64_t *__r
 
 struct StreamPackWs {
     uint64_t *nblk, *blk_base, *ext, *ext_scan, *scan_scratch, *blk_size, *blk_scan, *scan_scratch2;
+    uint32_t *blk_stream;
     size_t total;
 };
 static StreamPackWs carve_stream_pack(void *base, uint64_t n, uint64_t max_blocks) {
@@ -640,6 +634,7 @@ static StreamPackWs carve_stream_pack(void *base, uint64_t n, uint64_t max_block
     w.blk_size = (uint64_t *)take((max_blocks + 1) * 8);
     w.blk_scan = (uint64_t *)take((max_blocks + 1) * 8);
     w.scan_scratch2 = (uint64_t *)take(scan_scratch_words(max_blocks) * 8);
+    w.blk_stream = (uint32_t *)take((max_blocks + 1) * 4);
     w.total = off;
     return w;
 }
@@ -671,12 +666,13 @@ static hipError_t stream_pack_t(const uint64_t *d_values, const uint64_t *d_elem
     e = launch_exclusive_scan(w.ext, n, w.ext_scan, w.scan_scratch, stream);
     if (e != hipSuccess) return e;
     const uint32_t gb = (uint32_t)((maxb + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
-    if (maxb) k_stream_sizes<KIND><<<gb, ENC_THREADS, 0, stream>>>(d_values, d_elem_off, w.blk_base, n, maxb, w.blk_size);
+    if (n) k_enc_map<<<g, 256, 0, stream>>>(w.blk_base, n, w.blk_stream); // block -> stream
+    if (maxb) k_stream_sizes<KIND><<<gb, ENC_THREADS, 0, stream>>>(d_values, d_elem_off, w.blk_base, w.blk_stream, n, maxb, w.blk_size);
     e = launch_exclusive_scan(w.blk_size, maxb, w.blk_scan, w.scan_scratch2, stream);
     if (e != hipSuccess) return e;
     k_stream_offsets<<<g, 256, 0, stream>>>(KIND, d_values, d_elem_off, w.blk_base, w.blk_scan, w.ext_scan, n, d_bytes,
                                             d_byte_off, d_status, d_result);
-    if (maxb) k_stream_emit<KIND><<<gb, ENC_THREADS, 0, stream>>>(d_values, d_elem_off, w.blk_base, n, maxb, w.blk_scan,
+    if (maxb) k_stream_emit<KIND><<<gb, ENC_THREADS, 0, stream>>>(d_values, d_elem_off, w.blk_base, w.blk_stream, n, maxb, w.blk_scan,
                                                                   d_byte_off, d_bytes);
     return hipGetLastError();
 }

@@ -3,8 +3,8 @@
 //   pack_f64_xor + DoubleXorSink      (src/nibblepacking.rs:29-45, :284-325, :392-400)
 //   pack_u64 / unpack                 (src/nibblepacking.rs:68-93, :364-377)
 // A stream has no section structure: its octets form one serial chain, and the decoded values go
-// through a true element-to-element prefix sum / prefix XOR.  Unpack = index (one lane per stream
-// walks its octet chain once and cuts it into blocks of 32 octets) -> the section kernel decodes
+// through a true element-to-element prefix sum / prefix XOR.  Unpack = index (one wave per stream
+// walks its octet chain once, in LDS, and cuts it into blocks of 32 octets) -> the section kernel decodes
 // the blocks (K_RAW descriptors) -> per-block totals -> per-stream carries -> per-block wavefront
 // scan that writes the final values.  Pack = per-block sizes -> scans -> emit.
 #include "cvec_device.hpp"
@@ -29,17 +29,43 @@ __global__ void k_stream_nblk(int kind, const uint64_t *__restrict__ elem_off, u
 }
 
 // ---- unpack ---------------------------------------------------------------------------------------
-// One lane per stream: the serial octet chain of `unpack` (src/nibblepacking.rs:364-377), with the
-// checks of nibble_unpack8 (:418, :425) and "an octet must end inside the stream".  Writes one
-// K_RAW descriptor per block of 32 octets.
-__global__ __launch_bounds__(64) void k_stream_index(int kind, const uint8_t *__restrict__ bytes,
-                                                     const uint64_t *__restrict__ byte_off,
-                                                     const uint64_t *__restrict__ elem_off,
-                                                     const uint64_t *__restrict__ blk_base, uint64_t n,
-                                                     uint64_t padded_bytes, uint64_t *__restrict__ desc,
-                                                     int32_t *__restrict__ status) {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per stream: the serial octet chain of `unpack` (src/nibblepacking.rs:364-377), with the
+// checks of nibble_unpack8 (:418, :425) and "an octet must end inside the stream".  The chain is a
+// pointer chase (an octet's length is in its two header bytes).  The wave stages the stream through
+// LDS in tiles; for every byte position of the tile the lanes compute in parallel where an octet
+// starting there would end (a jump table), square the table three times (pointer doubling: 2, 4, 8
+// octets ahead), and then every lane follows the real chain eight octets per LDS read (uniform
+// addresses: LDS broadcasts).  Positions whose octet would leave the stream, or that the tile does
+// not cover, have no table entry: there the chain advances one octet at a time with the exact
+// checks.  The next tile is prefetched into registers.  Writes one K_RAW descriptor per block of 32
+// octets.
+constexpr int IDX_TILE = 1024;           // octets that start here are covered by the jump table
+constexpr int IDX_EXT = IDX_TILE + 128;  // staged bytes / table entries: an octet (<= 66 bytes) may end past the tile
+constexpr int IDX_WAVES = 4;
+static_assert(IDX_EXT % 64 == 0, "whole waves of table entries");
+constexpr int IDX_PRE = (IDX_TILE + 256) / 16; // 16-byte pieces prefetched behind the tile
+constexpr int IDX_PRE_REGS = (IDX_PRE + 63) / 64;
+constexpr uint32_t IDX_NONE = 0xffff;
+
+__device__ inline uint32_t octet_size(uint32_t mask, uint32_t word) {
+    return mask ? 2 + ((((word >> 4) + 1) * __popc(mask) + 1) >> 1) : 1;
+}
+
+__global__ __launch_bounds__(64 * IDX_WAVES) void k_stream_index(int kind, const uint8_t *__restrict__ bytes,
+                                                                 const uint64_t *__restrict__ byte_off,
+                                                                 const uint64_t *__restrict__ elem_off,
+                                                                 const uint64_t *__restrict__ blk_base, uint64_t n,
+                                                                 uint64_t padded_bytes, uint64_t *__restrict__ desc,
+                                                                 uint32_t *__restrict__ blk_stream,
+                                                                 int32_t *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[IDX_WAVES][IDX_EXT];
+    __shared__ uint16_t s_jump[IDX_WAVES][2][IDX_EXT];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t s = (uint64_t)blockIdx.x * IDX_WAVES + wave;
     if (s >= n) return;
+    uint8_t *tile = s_tile[wave];
+    uint16_t *ja = s_jump[wave][0], *jb = s_jump[wave][1];
     const uint64_t nval = elem_off[s + 1] - elem_off[s];
     const uint64_t start = byte_off[s], end = byte_off[s + 1];
     const uint64_t b0 = blk_base[s], nb = blk_base[s + 1] - b0;
@@ -51,26 +77,84 @@ __global__ __launch_bounds__(64) void k_stream_index(int kind, const uint8_t *__
         p += 8;
     }
     const uint64_t noct = (packed_values(kind, nval) + 7) / 8;
-    uint64_t blk = 0, blk_start = p;
-    for (uint64_t o = 0; o < noct && st == CVEC_OK; o++) {
+
+    auto piece = [&](uint64_t a) { // 16 bytes at the 16-aligned offset a, zeros past the padded blob
+        return a + 16 <= padded_bytes ? *(const uint4 *)(bytes + a) : make_uint4(0, 0, 0, 0);
+    };
+    uint64_t tile_base = 0, pre_base = 0;
+    uint4 pre[IDX_PRE_REGS];
+    bool have_pre = false;
+    // squares a jump table: dst[r] = src[src[r]]
+    auto hop = [&](const uint16_t *src, uint16_t *dst) {
+#pragma unroll
+        for (int k = 0; k < IDX_EXT / 64; k++) {
+            const uint32_t r = 64 * k + lane;
+            const uint32_t m = src[r];
+            dst[r] = m == IDX_NONE ? (uint16_t)IDX_NONE : src[m];
+        }
+    };
+    auto stage = [&]() {
+        tile_base = p & ~15ull;
+        if (!have_pre) {
+            for (uint32_t i = lane; i < IDX_EXT / 16; i += 64) ((uint4 *)tile)[i] = piece(tile_base + 16ull * i);
+        } else { // the chain left the old tile by less than an octet: the prefetched window covers the new one
+            const uint32_t shift = (uint32_t)((tile_base - pre_base) >> 4);
+#pragma unroll
+            for (int k = 0; k < IDX_PRE_REGS; k++) {
+                const uint32_t i = 64 * k + lane;
+                if (i < IDX_PRE && i >= shift && i - shift < IDX_EXT / 16) ((uint4 *)tile)[i - shift] = pre[k];
+            }
+        }
+        pre_base = tile_base + IDX_TILE;
+#pragma unroll
+        for (int k = 0; k < IDX_PRE_REGS; k++) pre[k] = piece(pre_base + 16ull * (64 * k + lane));
+        have_pre = true;
+        const uint64_t left = end - tile_base; // p < end here
+        const uint32_t end_rel = left < 0xffffu ? (uint32_t)left : 0xffffu;
+#pragma unroll
+        for (int k = 0; k < IDX_EXT / 64; k++) { // one octet ahead
+            const uint32_t r = 64 * k + lane;
+            uint32_t nx = IDX_NONE;
+            if (r < IDX_TILE) {
+                const uint32_t e = r + octet_size(tile[r], tile[r + 1]);
+                if (e <= end_rel) nx = e; // the octet lies inside the stream
+            }
+            ja[r] = (uint16_t)nx;
+        }
+        hop(ja, jb); // 2
+        hop(jb, ja); // 4
+        hop(ja, jb); // 8 octets ahead
+    };
+    uint64_t blk = 0, blk_start = p, o = 0;
+    bool staged = false;
+    while (o < noct && st == CVEC_OK) {
         if ((o & 31) == 0) blk_start = p;
         if (p >= end) { st = CVEC_NOT_ENOUGH_SPACE; break; }
-        // one 2-byte read per octet, pulled back inside the padded allocation at the very end
-        const uint64_t a = p + 2 <= padded_bytes ? p : padded_bytes - 2;
-        const uint32_t hw = (uint32_t)(*(const u16u *)(bytes + a)) >> (8 * (uint32_t)(p - a));
-        const uint32_t mask = hw & 0xffu;
-        uint64_t size = 1;
-        if (mask) {
-            if (end - p < 2) { st = CVEC_NOT_ENOUGH_SPACE; break; }
-            const uint32_t nn = ((hw >> 12) & 0xfu) + 1;
-            size = 2 + ((nn * __popc(mask) + 1) >> 1);
+        if (!staged || p - tile_base >= IDX_TILE) { stage(); staged = true; }
+        // every lane holds the same chain position: keep it in scalar registers
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p - tile_base));
+        const uint64_t want = noct - o < 32 - (o & 31) ? noct - o : 32 - (o & 31); // octets to the end of the block
+        const uint32_t far = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)jb[r]);
+        if (want >= 8 && far != IDX_NONE) {
+            p = tile_base + far;
+            o += 8;
+        } else {
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tile[r]);
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tile[r + 1]);
+            if (mask && end - p < 2) { st = CVEC_NOT_ENOUGH_SPACE; break; }
+            const uint64_t size = octet_size(mask, word);
             if (size > end - p) { st = CVEC_NOT_ENOUGH_SPACE; break; }
+            p += size;
+            o += 1;
         }
-        p += size;
-        if ((o & 31) == 31 || o + 1 == noct) desc[b0 + blk++] = desc_pack(blk_start, (uint32_t)(p - blk_start), K_RAW);
+        if ((o & 31) == 0 || o == noct) {
+            if (lane == 0) desc[b0 + blk] = desc_pack(blk_start, (uint32_t)(p - blk_start), K_RAW);
+            blk++;
+        }
     }
-    for (; blk < nb; blk++) desc[b0 + blk] = desc_pack(p < end ? p : end, 0, K_SKIP);
-    status[s] = st;
+    for (uint64_t i = blk + lane; i < nb; i += 64) desc[b0 + i] = desc_pack(p < end ? p : end, 0, K_SKIP);
+    for (uint64_t i = lane; i < nb; i += 64) blk_stream[b0 + i] = (uint32_t)s;
+    if (lane == 0) status[s] = st;
 }
 
 // Slots past the real block count (known only on the device) become empty K_SKIP descriptors at
@@ -134,6 +218,7 @@ __global__ void k_stream_carries(const uint8_t *__restrict__ bytes, const uint64
 template <int KIND>
 __global__ __launch_bounds__(256) void k_stream_scan_write(const uint64_t *__restrict__ raw,
                                                            const uint64_t *__restrict__ blk_base,
+                                                           const uint32_t *__restrict__ blk_stream,
                                                            const uint64_t *__restrict__ elem_off, uint64_t n,
                                                            uint64_t n_blocks, const uint64_t *__restrict__ carries,
                                                            const int32_t *__restrict__ status,
@@ -141,13 +226,8 @@ __global__ __launch_bounds__(256) void k_stream_scan_write(const uint64_t *__res
     const int lane = threadIdx.x & 63;
     const uint64_t blk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blk >= n_blocks) return;
-    // stream of this block: last s with blk_base[s] <= blk
-    uint64_t lo = 0, hi = n;
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (blk_base[mid] <= blk) lo = mid; else hi = mid;
-    }
-    const uint64_t s = lo;
+    if (blk >= blk_base[n]) return; // past the real block count
+    const uint64_t s = blk_stream[blk];
     if (status[s] != CVEC_OK) return;
     const uint64_t nval = elem_off[s + 1] - elem_off[s];
     const uint64_t shift = KIND == CVEC_STREAM_F64_XOR ? 1 : 0;
@@ -192,7 +272,7 @@ __global__ void k_stream_finish(const uint8_t *__restrict__ bytes, const uint64_
 
 struct StreamUnpackWs {
     uint64_t *nblk, *blk_base, *scan_scratch, *desc, *raw, *totals, *carries;
-    uint32_t *sec_res;
+    uint32_t *sec_res, *blk_stream;
     size_t total;
 };
 static inline size_t al256(size_t x) { return (x + 255) / 256 * 256; }
@@ -205,6 +285,7 @@ static StreamUnpackWs carve_unpack(void *base, uint64_t n, uint64_t max_blocks) 
     w.scan_scratch = (uint64_t *)(b + off); off += al256(scan_scratch_words(n) * 8);
     w.desc = (uint64_t *)(b + off); off += al256((max_blocks + 1) * 8);
     w.sec_res = (uint32_t *)(b + off); off += al256((max_blocks + 1) * 4);
+    w.blk_stream = (uint32_t *)(b + off); off += al256((max_blocks + 1) * 4);
     w.totals = (uint64_t *)(b + off); off += al256((max_blocks + 1) * 8);
     w.carries = (uint64_t *)(b + off); off += al256((max_blocks + 1) * 8);
     w.raw = (uint64_t *)(b + off); off += al256(max_blocks * FIXED_LEN * 8 + 64);
@@ -231,8 +312,8 @@ static hipError_t unpack_t(const uint8_t *d_bytes, const uint64_t *d_byte_off, u
     k_stream_nblk<<<g, 256, 0, stream>>>(KIND, d_elem_off, n, w.nblk);
     e = launch_exclusive_scan(w.nblk, n, w.blk_base, w.scan_scratch, stream);
     if (e != hipSuccess) return e;
-    k_stream_index<<<(uint32_t)((n + 63) / 64), 64, 0, stream>>>(KIND, d_bytes, d_byte_off, d_elem_off, w.blk_base, n,
-                                                                 (n_bytes + 15) & ~15ull, w.desc, d_status);
+    k_stream_index<<<(uint32_t)((n + IDX_WAVES - 1) / IDX_WAVES), 64 * IDX_WAVES, 0, stream>>>(KIND, d_bytes, d_byte_off, d_elem_off, w.blk_base, n,
+                                                                 (n_bytes + 15) & ~15ull, w.desc, w.blk_stream, d_status);
     // The block count is only known on the device; the section kernel runs over the upper bound and
     // skips the slots past the real count (their descriptors are K_SKIP).
     k_fill_skip<<<(uint32_t)((maxb + 255) / 256), 256, 0, stream>>>(w.blk_base + n, n_bytes, w.desc, maxb);
@@ -243,7 +324,7 @@ static hipError_t unpack_t(const uint8_t *d_bytes, const uint64_t *d_byte_off, u
     k_stream_carries<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, n, d_status, w.totals, w.carries);
     k_stream_finish<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, d_elem_off, n, w.sec_res, d_status, d_out,
                                                  d_result);
-    k_stream_scan_write<KIND><<<gb, 256, 0, stream>>>(w.raw, w.blk_base, d_elem_off, n, maxb, w.carries, d_status, d_out);
+    k_stream_scan_write<KIND><<<gb, 256, 0, stream>>>(w.raw, w.blk_base, w.blk_stream, d_elem_off, n, maxb, w.carries, d_status, d_out);
     return hipGetLastError();
 }
 
