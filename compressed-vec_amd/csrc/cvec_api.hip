@@ -2,6 +2,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <algorithm>
 #include <vector>
 
 #include "cvec_device.hpp"
@@ -69,39 +72,229 @@ static inline int elem_width(int32_t t) { return t == CVEC_U64 ? 8 : 4; }
 namespace {
 struct DevBuf {
     void *p = nullptr;
+    size_t cap = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t alloc(size_t n) { // grow-only: a buffer that is large enough is kept
+        n = n ? n : 16;
+        if (p && cap >= n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
     template <class T> T *as() { return (T *)p; }
 };
 
-// Uploads blob + offsets and builds sec_base; fills `view`.
-cvec_status upload_batch(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off, uint64_t n,
-                         DevBuf &bytes, DevBuf &boff, DevBuf &sbase, cvec_dbatch_view *view) {
-    if (!etype_ok(etype) || !h_byte_off || (n && !h_bytes)) return CVEC_ERR_BAD_ARGUMENT;
-    for (uint64_t v = 0; v < n; v++)
-        if (h_byte_off[v + 1] < h_byte_off[v]) return CVEC_ERR_BAD_ARGUMENT;
-    const uint64_t nbytes = h_byte_off[n];
-    HIP_TRY(bytes.alloc(align_up(nbytes + 16, 256)));
-    HIP_TRY(boff.alloc((n + 1) * 8));
-    HIP_TRY(sbase.alloc((n + 1) * 8));
-    if (nbytes) HIP_TRY(hipMemcpy(bytes.p, h_bytes, nbytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(boff.p, h_byte_off, (n + 1) * 8, hipMemcpyHostToDevice));
-    uint64_t nsec = 0;
-    cvec_status st = cvec_sec_base_dev(bytes.as<uint8_t>(), boff.as<uint64_t>(), n, sbase.as<uint64_t>(), &nsec, nullptr);
-    if (st) return st;
-    view->etype = etype;
-    view->_pad = 0;
-    view->n_vectors = n;
-    view->n_sections = nsec;
-    view->n_bytes = nbytes;
-    view->d_bytes = bytes.as<uint8_t>();
-    view->d_byte_off = boff.as<uint64_t>();
-    view->d_sec_base = sbase.as<uint64_t>();
-    return CVEC_OK;
+struct PinBuf { // page-locked host memory, grow-only like DevBuf
+    void *p = nullptr;
+    size_t cap = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    hipError_t alloc(size_t n) {
+        n = n ? n : 16;
+        if (p && cap >= n) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+struct StreamBox {
+    hipStream_t s = nullptr;
+    StreamBox() = default;
+    StreamBox(const StreamBox &) = delete;
+    StreamBox &operator=(StreamBox &&o) { if (s) (void)hipStreamDestroy(s); s = o.s; o.s = nullptr; return *this; }
+    ~StreamBox() { if (s) (void)hipStreamDestroy(s); }
+    hipError_t make() { return s ? hipSuccess : hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+};
+
+constexpr size_t PIPE_SLOTS = 3;
+size_t pipe_chunk_bytes() {
+    const char *e = getenv("CVEC_PIPE_CHUNK_BYTES");
+    const unsigned long long v = e ? strtoull(e, nullptr, 10) : 0;
+    return v ? (size_t)v : (size_t)64 << 20;
+}
+
+// Chunk c = vectors [first[c], first[c+1]): consecutive vectors whose weights add up to at most
+// `target` (a vector heavier than that is a chunk of its own).
+template <class Weight> std::vector<uint64_t> plan_chunks(uint64_t n, size_t target, Weight weight) {
+    std::vector<uint64_t> first{0};
+    uint64_t acc = 0;
+    for (uint64_t v = 0; v < n; v++) {
+        const uint64_t wv = weight(v);
+        if (v > first.back() && acc + wv > target) { first.push_back(v); acc = 0; }
+        acc += wv;
+    }
+    if (n) first.push_back(n);
+    return first;
 }
 
 cvec_status summary_status(const uint64_t res[CVEC_RESULT_WORDS]) {
     return res[1] ? (cvec_status)res[2] : CVEC_OK;
+}
+
+struct EventBox {
+    hipEvent_t e = nullptr;
+    ~EventBox() { if (e) (void)hipEventDestroy(e); }
+    hipError_t make() { return e ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+};
+struct ReadSlot {
+    DevBuf bytes, boff, sbase, ws, res, per, stt, out;
+    PinBuf hoff, hres, hper, hstt; // small arrays go through page-locked staging: a copy to pageable memory blocks the host
+    EventBox ev_in, ev_run, ev_out; // copy-in done, kernels done, copy-out done
+    bool busy = false;
+    uint64_t v0 = 0, nv = 0;        // the vectors of the chunk in flight
+};
+struct EncSlot {
+    DevBuf vals, eoff, bytes, boff, sbase, ws, res;
+    PinBuf heoff, hres, hboff;
+    EventBox ev_in, ev_run, ev_res, ev_out; // copy-in, encode, result block on the host, blob copied out
+    size_t chunk = (size_t)-1;             // encoded, blob not yet requested
+    size_t leaving = (size_t)-1;           // blob and offsets on their way to the host
+};
+// The pipeline of the calling thread on the current device (dropped when the device changes): one
+// stream per role - copies in, kernels, copies out - because on this platform transfers in the two
+// PCIe directions only run at the same time when they come from different streams that each copy
+// one way; the slots hand a chunk from stream to stream through events.
+template <class S> struct SlotCache {
+    int device = -1;
+    std::vector<S> slots;
+    StreamBox s_in, s_run, s_out;
+    S *get() {
+        int d = -1;
+        if (hipGetDevice(&d) != hipSuccess) return nullptr;
+        if (d != device) { slots.clear(); s_in = StreamBox(); s_run = StreamBox(); s_out = StreamBox(); device = d; }
+        if (slots.empty()) slots = std::vector<S>(PIPE_SLOTS);
+        if (s_in.make() != hipSuccess || s_run.make() != hipSuccess || s_out.make() != hipSuccess) return nullptr;
+        return slots.data();
+    }
+};
+
+// filter + count (decode == false) or decode through the sink chain (decode == true) of a batch in
+// host memory, chunk by chunk.  `r` receives the summed result block.
+cvec_status read_pipeline(bool decode, int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off, uint64_t n,
+                          const cvec_pred *pred, const cvec_sink_chain *chain, uint64_t r[CVEC_RESULT_WORDS],
+                          uint64_t *h_per_vector, int32_t *h_status, void *h_out, uint64_t out_cap_elems,
+                          uint64_t *h_out_off) {
+    if (!etype_ok(etype) || !h_byte_off || (n && !h_bytes)) return CVEC_ERR_BAD_ARGUMENT;
+    for (uint64_t v = 0; v < n; v++)
+        if (h_byte_off[v + 1] < h_byte_off[v]) return CVEC_ERR_BAD_ARGUMENT;
+    const int w = elem_width(etype);
+    // sections per vector from the headers (u32 num_elements at +8, reference src/vector.rs:165)
+    std::vector<uint64_t> sec_base(n + 1, 0);
+    for (uint64_t v = 0; v < n; v++) {
+        uint64_t c = 0;
+        if (h_byte_off[v + 1] - h_byte_off[v] >= (uint64_t)HEADER_BYTES) {
+            uint32_t ne;
+            memcpy(&ne, h_bytes + h_byte_off[v] + 8, 4);
+            c = ((uint64_t)ne + FIXED_LEN - 1) / FIXED_LEN;
+        }
+        sec_base[v + 1] = sec_base[v] + c;
+    }
+    if (decode) {
+        if (h_out_off)
+            for (uint64_t v = 0; v <= n; v++) h_out_off[v] = sec_base[v] * FIXED_LEN;
+        const uint64_t n_out = sec_base[n] * FIXED_LEN;
+        if (n_out > out_cap_elems || (n_out && !h_out)) return CVEC_NOT_ENOUGH_SPACE;
+    }
+    const std::vector<uint64_t> first = plan_chunks(n, pipe_chunk_bytes(), [&](uint64_t v) {
+        return h_byte_off[v + 1] - h_byte_off[v] + 16 + (decode ? (sec_base[v + 1] - sec_base[v]) * FIXED_LEN * w : 0);
+    });
+    const size_t nchunks = first.size() - 1;
+    uint64_t max_vec = 0, max_bytes = 0, max_sec = 0;
+    for (size_t c = 0; c < nchunks; c++) {
+        max_vec = std::max(max_vec, first[c + 1] - first[c]);
+        max_bytes = std::max(max_bytes, h_byte_off[first[c + 1]] - h_byte_off[first[c]]);
+        max_sec = std::max(max_sec, sec_base[first[c + 1]] - sec_base[first[c]]);
+    }
+    const size_t nslots = std::min<size_t>(PIPE_SLOTS, std::max<size_t>(nchunks, 1));
+    // The slots (device buffers, pinned offsets, streams) are kept per host thread and device and only
+    // grow: allocating them costs as much as moving tens of MiB over PCIe.  They are never freed (a
+    // destructor at thread or process exit could run after the HIP runtime has shut down).
+    static thread_local SlotCache<ReadSlot> *cache = new SlotCache<ReadSlot>();
+    ReadSlot *slots = cache->get();
+    if (!slots) return hip_fail(hipGetLastError(), "pipeline streams");
+    hipStream_t s_in = cache->s_in.s, s_run = cache->s_run.s, s_out = cache->s_out.s;
+    const size_t wsb = cvec_workspace_bytes(max_vec, max_sec);
+    for (size_t k = 0; k < nslots; k++) {
+        ReadSlot &sl = slots[k];
+        sl.busy = false;
+        HIP_TRY(sl.bytes.alloc(align_up(max_bytes + 16, 256)));
+        HIP_TRY(sl.boff.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.sbase.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.ws.alloc(wsb));
+        HIP_TRY(sl.res.alloc(CVEC_RESULT_WORDS * 8));
+        if (h_per_vector) { HIP_TRY(sl.per.alloc(max_vec * 8)); HIP_TRY(sl.hper.alloc(max_vec * 8)); }
+        if (h_status) { HIP_TRY(sl.stt.alloc(max_vec * 4)); HIP_TRY(sl.hstt.alloc(max_vec * 4)); }
+        if (decode) HIP_TRY(sl.out.alloc(max_sec * FIXED_LEN * w));
+        HIP_TRY(sl.hoff.alloc(2 * (max_vec + 1) * 8));
+        HIP_TRY(sl.hres.alloc(CVEC_RESULT_WORDS * 8));
+        HIP_TRY(sl.ev_in.make());
+        HIP_TRY(sl.ev_run.make());
+        HIP_TRY(sl.ev_out.make());
+    }
+    auto collect = [&](ReadSlot &sl) -> cvec_status { // waits for the slot's chunk and folds its result block in
+        if (!sl.busy) return CVEC_OK;
+        HIP_TRY(hipEventSynchronize(sl.ev_out.e));
+        sl.busy = false;
+        if (h_per_vector && sl.nv) memcpy(h_per_vector + sl.v0, sl.hper.p, sl.nv * 8);
+        if (h_status && sl.nv) memcpy(h_status + sl.v0, sl.hstt.p, sl.nv * 4);
+        const uint64_t *q = (const uint64_t *)sl.hres.p;
+        r[0] += q[0];
+        r[1] += q[1];
+        r[2] = std::max(r[2], q[2]);
+        r[3] += q[3];
+        return CVEC_OK;
+    };
+    for (size_t c = 0; c < nchunks; c++) {
+        ReadSlot &sl = slots[c % nslots];
+        cvec_status st = collect(sl);
+        if (st) return st;
+        const uint64_t v0 = first[c], nv = first[c + 1] - v0;
+        const uint64_t b0 = h_byte_off[v0], nbytes = h_byte_off[first[c + 1]] - b0;
+        const uint64_t s0 = sec_base[v0], nsec = sec_base[first[c + 1]] - s0;
+        uint64_t *bo = (uint64_t *)sl.hoff.p, *sb = bo + (nv + 1);
+        for (uint64_t i = 0; i <= nv; i++) { bo[i] = h_byte_off[v0 + i] - b0; sb[i] = sec_base[v0 + i] - s0; }
+        if (nbytes) HIP_TRY(hipMemcpyAsync(sl.bytes.p, h_bytes + b0, nbytes, hipMemcpyHostToDevice, s_in));
+        HIP_TRY(hipMemcpyAsync(sl.boff.p, bo, (nv + 1) * 8, hipMemcpyHostToDevice, s_in));
+        HIP_TRY(hipMemcpyAsync(sl.sbase.p, sb, (nv + 1) * 8, hipMemcpyHostToDevice, s_in));
+        HIP_TRY(hipEventRecord(sl.ev_in.e, s_in));
+        HIP_TRY(hipStreamWaitEvent(s_run, sl.ev_in.e, 0));
+        cvec_dbatch_view view;
+        view.etype = etype;
+        view._pad = 0;
+        view.n_vectors = nv;
+        view.n_sections = nsec;
+        view.n_bytes = nbytes;
+        view.d_bytes = sl.bytes.as<uint8_t>();
+        view.d_byte_off = sl.boff.as<uint64_t>();
+        view.d_sec_base = sl.sbase.as<uint64_t>();
+        if (decode) {
+            if (nsec) HIP_TRY(hipMemsetAsync(sl.out.p, 0, nsec * FIXED_LEN * w, s_run));
+            st = cvec_decode_dev(&view, chain, sl.out.p, sl.res.as<uint64_t>(), h_status ? sl.stt.as<int32_t>() : nullptr,
+                                 sl.ws.p, wsb, s_run);
+        } else {
+            st = cvec_filter_count_dev(&view, pred, sl.res.as<uint64_t>(), h_per_vector ? sl.per.as<uint64_t>() : nullptr,
+                                       h_status ? sl.stt.as<int32_t>() : nullptr, nullptr, sl.ws.p, wsb, s_run);
+        }
+        if (st) return st;
+        HIP_TRY(hipEventRecord(sl.ev_run.e, s_run));
+        HIP_TRY(hipStreamWaitEvent(s_out, sl.ev_run.e, 0));
+        HIP_TRY(hipMemcpyAsync(sl.hres.p, sl.res.p, CVEC_RESULT_WORDS * 8, hipMemcpyDeviceToHost, s_out));
+        if (h_per_vector && nv) HIP_TRY(hipMemcpyAsync(sl.hper.p, sl.per.p, nv * 8, hipMemcpyDeviceToHost, s_out));
+        if (h_status && nv) HIP_TRY(hipMemcpyAsync(sl.hstt.p, sl.stt.p, nv * 4, hipMemcpyDeviceToHost, s_out));
+        sl.v0 = v0;
+        sl.nv = nv;
+        if (decode && nsec)
+            HIP_TRY(hipMemcpyAsync((uint8_t *)h_out + s0 * FIXED_LEN * w, sl.out.p, nsec * FIXED_LEN * w,
+                                   hipMemcpyDeviceToHost, s_out));
+        HIP_TRY(hipEventRecord(sl.ev_out.e, s_out));
+        sl.busy = true;
+    }
+    for (size_t k = 0; k < nslots; k++) {
+        cvec_status st = collect(slots[k]);
+        if (st) return st;
+    }
+    return CVEC_OK;
 }
 } // namespace
 
@@ -402,29 +595,22 @@ cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t 
     return CVEC_OK;
 }
 
-// ---- host-buffer convenience -------------------------------------------------------------------
-
+// ---- host-buffer entry points --------------------------------------------------------------------
+// The batch is cut into chunks of whole vectors (about 64 MiB each; CVEC_PIPE_CHUNK_BYTES overrides,
+// read per call) that rotate through PIPE_SLOTS slots of device buffers and pass from a copy-in
+// stream to a kernel stream to a copy-out stream: the copy-in of one chunk, the kernels of another
+// and the copy-out of a third overlap, and the two PCIe directions run at the same time.  Copies from or to pageable host memory are staged by the
+// runtime and overlap little; page-locked caller buffers (hipHostMalloc / hipHostRegister) get the
+// full effect.  A batch of one chunk behaves like a plain upload - run - download.
 
 cvec_status cvec_filter_count_batch(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off,
                                     uint64_t n_vectors, const cvec_pred *pred, uint64_t *h_total,
                                     uint64_t *h_per_vector, int32_t *h_status) {
-    if (!h_total) return CVEC_ERR_BAD_ARGUMENT;
-    DevBuf bytes, boff, sbase, ws, res, per, stt;
-    cvec_dbatch_view view;
-    cvec_status st = upload_batch(etype, h_bytes, h_byte_off, n_vectors, bytes, boff, sbase, &view);
+    if (!h_total || !pred) return CVEC_ERR_BAD_ARGUMENT;
+    uint64_t r[CVEC_RESULT_WORDS] = {0, 0, 0, 0};
+    cvec_status st = read_pipeline(false, etype, h_bytes, h_byte_off, n_vectors, pred, nullptr, r, h_per_vector, h_status,
+                                   nullptr, 0, nullptr);
     if (st) return st;
-    const size_t wsb = cvec_workspace_bytes(view.n_vectors, view.n_sections);
-    HIP_TRY(ws.alloc(wsb));
-    HIP_TRY(res.alloc(CVEC_RESULT_WORDS * 8));
-    if (h_per_vector) HIP_TRY(per.alloc(n_vectors * 8));
-    if (h_status) HIP_TRY(stt.alloc(n_vectors * 4));
-    st = cvec_filter_count_dev(&view, pred, res.as<uint64_t>(), h_per_vector ? per.as<uint64_t>() : nullptr,
-                               h_status ? stt.as<int32_t>() : nullptr, nullptr, ws.p, wsb, nullptr);
-    if (st) return st;
-    uint64_t r[CVEC_RESULT_WORDS];
-    HIP_TRY(hipMemcpy(r, res.p, sizeof(r), hipMemcpyDeviceToHost));
-    if (h_per_vector && n_vectors) HIP_TRY(hipMemcpy(h_per_vector, per.p, n_vectors * 8, hipMemcpyDeviceToHost));
-    if (h_status && n_vectors) HIP_TRY(hipMemcpy(h_status, stt.p, n_vectors * 4, hipMemcpyDeviceToHost));
     *h_total = r[0];
     return summary_status(r);
 }
@@ -432,31 +618,10 @@ cvec_status cvec_filter_count_batch(int32_t etype, const uint8_t *h_bytes, const
 cvec_status cvec_decode_batch(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off, uint64_t n_vectors,
                               const cvec_sink_chain *chain, void *h_out, uint64_t out_cap_elems, uint64_t *h_out_off,
                               int32_t *h_status) {
-    DevBuf bytes, boff, sbase, ws, res, out, stt;
-    cvec_dbatch_view view;
-    cvec_status st = upload_batch(etype, h_bytes, h_byte_off, n_vectors, bytes, boff, sbase, &view);
+    uint64_t r[CVEC_RESULT_WORDS] = {0, 0, 0, 0};
+    cvec_status st = read_pipeline(true, etype, h_bytes, h_byte_off, n_vectors, nullptr, chain, r, nullptr, h_status, h_out,
+                                   out_cap_elems, h_out_off);
     if (st) return st;
-    const uint64_t n_out = view.n_sections * FIXED_LEN;
-    if (h_out_off) {
-        std::vector<uint64_t> sb(n_vectors + 1);
-        HIP_TRY(hipMemcpy(sb.data(), sbase.p, (n_vectors + 1) * 8, hipMemcpyDeviceToHost));
-        for (uint64_t v = 0; v <= n_vectors; v++) h_out_off[v] = sb[v] * FIXED_LEN;
-    }
-    if (n_out > out_cap_elems || (n_out && !h_out)) return CVEC_NOT_ENOUGH_SPACE;
-    const size_t wsb = cvec_workspace_bytes(view.n_vectors, view.n_sections);
-    const int w = elem_width(etype);
-    HIP_TRY(ws.alloc(wsb));
-    HIP_TRY(res.alloc(CVEC_RESULT_WORDS * 8));
-    HIP_TRY(out.alloc(n_out * w));
-    if (h_status) HIP_TRY(stt.alloc(n_vectors * 4));
-    HIP_TRY(hipMemset(out.p, 0, n_out * w));
-    st = cvec_decode_dev(&view, chain, out.p, res.as<uint64_t>(), h_status ? stt.as<int32_t>() : nullptr, ws.p, wsb,
-                         nullptr);
-    if (st) return st;
-    uint64_t r[CVEC_RESULT_WORDS];
-    HIP_TRY(hipMemcpy(r, res.p, sizeof(r), hipMemcpyDeviceToHost));
-    if (n_out) HIP_TRY(hipMemcpy(h_out, out.p, n_out * w, hipMemcpyDeviceToHost));
-    if (h_status && n_vectors) HIP_TRY(hipMemcpy(h_status, stt.p, n_vectors * 4, hipMemcpyDeviceToHost));
     return summary_status(r);
 }
 
@@ -468,31 +633,115 @@ cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_
         // finish(): total_num_rows > u32::MAX is InvalidNumRows (reference src/vector.rs:347-349)
         if (h_elem_off[v + 1] - h_elem_off[v] > 0xffffffffull) return CVEC_INVALID_NUM_ROWS;
     }
-    const uint64_t n_el = h_elem_off[n_vectors] - h_elem_off[0];
+    if (h_elem_off[n_vectors] > h_elem_off[0] && !h_values) return CVEC_ERR_BAD_ARGUMENT;
     const int w = elem_width(etype);
-    DevBuf vals, eoff, bytes, boff, sbase, ws, res;
-    const size_t cap = cvec_max_encoded_bytes(etype, n_vectors, n_el);
-    const size_t wsb = cvec_encode_workspace_bytes(n_vectors, n_el);
-    HIP_TRY(vals.alloc(n_el * w + 16));
-    HIP_TRY(eoff.alloc((n_vectors + 1) * 8));
-    HIP_TRY(bytes.alloc(align_up(cap, 256)));
-    HIP_TRY(boff.alloc((n_vectors + 1) * 8));
-    HIP_TRY(sbase.alloc((n_vectors + 1) * 8));
-    HIP_TRY(ws.alloc(wsb));
-    HIP_TRY(res.alloc(CVEC_RESULT_WORDS * 8));
-    std::vector<uint64_t> eo(n_vectors + 1);
-    for (uint64_t v = 0; v <= n_vectors; v++) eo[v] = h_elem_off[v] - h_elem_off[0];
-    if (n_el) HIP_TRY(hipMemcpy(vals.p, (const uint8_t *)h_values + h_elem_off[0] * w, n_el * w, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(eoff.p, eo.data(), (n_vectors + 1) * 8, hipMemcpyHostToDevice));
-    cvec_status st = cvec_encode_dev(etype, vals.p, eoff.as<uint64_t>(), n_vectors, n_el, bytes.as<uint8_t>(), cap,
-                                     boff.as<uint64_t>(), sbase.as<uint64_t>(), res.as<uint64_t>(), ws.p, wsb, nullptr);
-    if (st) return st;
-    uint64_t r[CVEC_RESULT_WORDS];
-    HIP_TRY(hipMemcpy(r, res.p, sizeof(r), hipMemcpyDeviceToHost));
-    if (h_total_bytes) *h_total_bytes = r[0];
-    if (r[0] > bytes_cap) return CVEC_NOT_ENOUGH_SPACE;
-    if (r[0]) HIP_TRY(hipMemcpy(h_bytes, bytes.p, r[0], hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_byte_off, boff.p, (n_vectors + 1) * 8, hipMemcpyDeviceToHost));
+    // chunk weight: the values plus a little per vector (headers, offsets)
+    const std::vector<uint64_t> first = plan_chunks(n_vectors, pipe_chunk_bytes(), [&](uint64_t v) {
+        return (h_elem_off[v + 1] - h_elem_off[v]) * (uint64_t)w + 64;
+    });
+    const size_t nchunks = first.size() - 1;
+    uint64_t max_vec = 0, max_el = 0;
+    for (size_t c = 0; c < nchunks; c++) {
+        max_vec = std::max(max_vec, first[c + 1] - first[c]);
+        max_el = std::max(max_el, h_elem_off[first[c + 1]] - h_elem_off[first[c]]);
+    }
+    const size_t nslots = std::min<size_t>(PIPE_SLOTS, std::max<size_t>(nchunks, 1));
+    static thread_local SlotCache<EncSlot> *cache = new SlotCache<EncSlot>();
+    EncSlot *slots = cache->get();
+    if (!slots) return hip_fail(hipGetLastError(), "pipeline streams");
+    hipStream_t s_in = cache->s_in.s, s_run = cache->s_run.s, s_out = cache->s_out.s;
+    const size_t cap = cvec_max_encoded_bytes(etype, max_vec, max_el);
+    const size_t wsb = cvec_encode_workspace_bytes(max_vec, max_el);
+    for (size_t k = 0; k < nslots; k++) {
+        EncSlot &sl = slots[k];
+        sl.chunk = sl.leaving = (size_t)-1;
+        HIP_TRY(sl.hboff.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.vals.alloc(max_el * w + 16));
+        HIP_TRY(sl.eoff.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.bytes.alloc(align_up(cap, 256)));
+        HIP_TRY(sl.boff.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.sbase.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.ws.alloc(wsb));
+        HIP_TRY(sl.res.alloc(CVEC_RESULT_WORDS * 8));
+        HIP_TRY(sl.heoff.alloc((max_vec + 1) * 8));
+        HIP_TRY(sl.hres.alloc(CVEC_RESULT_WORDS * 8));
+        HIP_TRY(sl.ev_in.make());
+        HIP_TRY(sl.ev_run.make());
+        HIP_TRY(sl.ev_res.make());
+        HIP_TRY(sl.ev_out.make());
+        HIP_TRY(hipEventRecord(sl.ev_out.e, s_out)); // nothing to wait for before the slot's first use
+    }
+    uint64_t total = 0;
+    bool overflow = false;
+    std::vector<uint64_t> base(nchunks, 0); // blob offset of each chunk's first byte
+    // The blob offset of a chunk is the size of everything before it, which the host learns when the
+    // earlier chunks have been encoded: a chunk's bytes are fetched when its slot comes up again,
+    // PIPE_SLOTS - 1 chunks later; the slot's next encode waits for that copy.
+    auto land = [&](EncSlot &sl) -> cvec_status { // the offsets of the chunk whose blob was requested last
+        if (sl.leaving == (size_t)-1) return CVEC_OK;
+        HIP_TRY(hipEventSynchronize(sl.ev_out.e));
+        const size_t c = sl.leaving;
+        sl.leaving = (size_t)-1;
+        const uint64_t *bo = (const uint64_t *)sl.hboff.p;
+        for (uint64_t v = first[c]; v < first[c + 1]; v++) h_byte_off[v] = base[c] + bo[v - first[c]];
+        return CVEC_OK;
+    };
+    auto collect = [&](EncSlot &sl) -> cvec_status {
+        cvec_status ls = land(sl);
+        if (ls) return ls;
+        if (sl.chunk == (size_t)-1) return CVEC_OK;
+        HIP_TRY(hipEventSynchronize(sl.ev_res.e));
+        const size_t c = sl.chunk;
+        sl.chunk = (size_t)-1;
+        const uint64_t size = ((const uint64_t *)sl.hres.p)[0];
+        const uint64_t nv = first[c + 1] - first[c];
+        base[c] = total;
+        if (total + size > bytes_cap) overflow = true;
+        else {
+            if (size) HIP_TRY(hipMemcpyAsync(h_bytes + total, sl.bytes.p, size, hipMemcpyDeviceToHost, s_out));
+            if (nv) HIP_TRY(hipMemcpyAsync(sl.hboff.p, sl.boff.p, nv * 8, hipMemcpyDeviceToHost, s_out));
+            sl.leaving = c;
+        }
+        HIP_TRY(hipEventRecord(sl.ev_out.e, s_out));
+        total += size;
+        return CVEC_OK;
+    };
+    for (size_t c = 0; c < nchunks; c++) {
+        EncSlot &sl = slots[c % nslots];
+        cvec_status st = collect(sl);
+        if (st) return st;
+        // the slot's pinned offsets may still feed its previous copy-in only until that chunk ran: collect() synchronised
+        const uint64_t v0 = first[c], nv = first[c + 1] - v0;
+        const uint64_t e0 = h_elem_off[v0], n_el = h_elem_off[first[c + 1]] - e0;
+        uint64_t *eo = (uint64_t *)sl.heoff.p;
+        for (uint64_t i = 0; i <= nv; i++) eo[i] = h_elem_off[v0 + i] - e0;
+        if (n_el) HIP_TRY(hipMemcpyAsync(sl.vals.p, (const uint8_t *)h_values + e0 * w, n_el * w, hipMemcpyHostToDevice, s_in));
+        HIP_TRY(hipMemcpyAsync(sl.eoff.p, eo, (nv + 1) * 8, hipMemcpyHostToDevice, s_in));
+        HIP_TRY(hipEventRecord(sl.ev_in.e, s_in));
+        HIP_TRY(hipStreamWaitEvent(s_run, sl.ev_in.e, 0));
+        HIP_TRY(hipStreamWaitEvent(s_run, sl.ev_out.e, 0)); // the slot's previous blob has left the device buffer
+        st = cvec_encode_dev(etype, sl.vals.p, sl.eoff.as<uint64_t>(), nv, n_el, sl.bytes.as<uint8_t>(), cap,
+                             sl.boff.as<uint64_t>(), sl.sbase.as<uint64_t>(), sl.res.as<uint64_t>(), sl.ws.p, wsb, s_run);
+        if (st) return st;
+        HIP_TRY(hipEventRecord(sl.ev_run.e, s_run));
+        HIP_TRY(hipStreamWaitEvent(s_out, sl.ev_run.e, 0));
+        HIP_TRY(hipMemcpyAsync(sl.hres.p, sl.res.p, CVEC_RESULT_WORDS * 8, hipMemcpyDeviceToHost, s_out));
+        HIP_TRY(hipEventRecord(sl.ev_res.e, s_out));
+        sl.chunk = c;
+    }
+    // the chunks still in flight, oldest first
+    for (size_t k = 0; k < nslots; k++) {
+        cvec_status st = collect(slots[(nchunks + k) % nslots]);
+        if (st) return st;
+    }
+    for (size_t k = 0; k < nslots; k++) {
+        cvec_status st = land(slots[k]);
+        if (st) return st;
+    }
+    HIP_TRY(hipStreamSynchronize(s_out));
+    if (h_total_bytes) *h_total_bytes = total;
+    if (overflow) return CVEC_NOT_ENOUGH_SPACE;
+    h_byte_off[n_vectors] = total;
     return CVEC_OK;
 }
 

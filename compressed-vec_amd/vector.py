@@ -81,6 +81,16 @@ class VectorAppender:
         self.reset()
         return bytes(out)
 
+    def reader(self):
+        """Reader over what has been written so far (src/vector.rs:372-378): the complete sections;
+        values still in the 256-element write buffer are not visible yet."""
+        flushed = self._len - self._wbuf
+        vals = np.concatenate(self._chunks)[:flushed] if self._chunks else np.zeros(0, dtype=NP_DTYPE[self.etype])
+        batch = encode_batch(self.etype, vals, np.array([0, flushed], dtype=np.uint64))
+        out = bytearray(batch.vector(0))
+        out[12:14] = int(self._null_sections & 0xffff).to_bytes(2, "little")
+        return VectorReader.try_new(bytes(out), self.etype)
+
     def encode_all(self, collection):
         self.append_many(np.fromiter(collection, dtype=NP_DTYPE[self.etype]) if not isinstance(
             collection, np.ndarray) else collection)

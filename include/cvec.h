@@ -220,8 +220,17 @@ cvec_status cvec_stream_unpack_dev(int32_t kind, const uint8_t *d_bytes, const u
                                    uint64_t *d_out, int32_t *d_status, uint64_t *d_result, void *d_workspace,
                                    size_t workspace_bytes, void *stream);
 
-/* ---- host-buffer convenience (what a Rust ffi.rs shim behind the unchanged crate API calls) -- */
-/* Each call uploads through pinned staging, runs the _dev operation and downloads the result.   */
+/* ---- host-buffer entry points (what a Rust ffi.rs shim behind the unchanged crate API calls) -- */
+/* The batch is cut into chunks of whole vectors (about 64 MiB; the environment variable
+ * CVEC_PIPE_CHUNK_BYTES, read per call, overrides) that rotate through three slots of device
+ * buffers and pass from a copy-in stream to a kernel stream to a copy-out stream, so the upload
+ * of one chunk, the kernels of another and the download of a third overlap and both PCIe
+ * directions are busy at once.  Page-locked caller buffers (hipHostMalloc / hipHostRegister) get
+ * the full overlap; copies from or to pageable memory are staged by the runtime and block.
+ * The slots, their pinned staging and the three streams are kept per calling thread and device
+ * and only grow.  Results equal those of one _dev call over the whole batch.  These replace the
+ * per-vector calls of the crate API (src/vector.rs:238-246 encode_all, :447 filter_iter +
+ * src/filter.rs:296 count_hits, src/vector.rs:458-464 decode_to_sink) for n_vectors at a time. */
 
 cvec_status cvec_filter_count_batch(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off,
                                     uint64_t n_vectors, const cvec_pred *pred, uint64_t *h_total,

@@ -225,6 +225,19 @@ def test_reference_test_cases_through_the_api_mirror(cv):
     assert list(vecsink.vec[:4]) == [3.5, 4.0, 4.5, 5.0]
 
 
+def test_appender_reader_sees_complete_sections_only(cv):
+    """VectorAppender::reader (src/vector.rs:372-378) reads what has been encoded so far."""
+    app = cv.VectorU32Appender.try_new(1024)
+    app.append_many(np.arange(1, 301, dtype=np.uint32))
+    r = app.reader()
+    assert r.num_elements() == 256 and np.array_equal(r.iterate(), np.arange(1, 257, dtype=np.uint32))
+    app.append_nulls(256 - 44 + 256)                 # fills the open section, then one explicit null section
+    r = app.reader()
+    assert r.num_elements() == 768 and r.get_stats()["num_null_sections"] == 1
+    assert np.array_equal(r.iterate()[:300], np.arange(1, 301, dtype=np.uint32)) and not r.iterate()[300:].any()
+    assert cv.VectorU32Appender.try_new(64).reader().num_elements() == 0
+
+
 def test_mixed_null_appender_bytes_match_oracle(cv, oracle):
     # src/vector.rs:601-634, :637-666: explicit null sections are counted in the header
     for cap, d1n, nulls, d2n in [(1024, 100, (256 - 100) + 256 + 50, 50), (300, 300, 350, 300)]:
@@ -452,6 +465,47 @@ def test_large_ragged_batch_vs_oracle(cv, oracle, tname):
         total, per = dev.filter_count(p, per_vector=True)
         wtotal, wper, wst, rc = oracle.batch_filter_count(ET[tname], blob, bo, p)
         assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+
+
+@pytest.mark.parametrize("chunk_bytes", ["3000", "70000", None])
+def test_host_buffer_entry_points_chunked_vs_oracle(cv, oracle, monkeypatch, chunk_bytes):
+    """cvec_{encode,decode,filter_count}_batch on host arrays: the library pipelines chunks of whole
+    vectors through a few device slots; tiny chunks (many per batch, some a single vector), medium
+    ones and the default (one chunk) must all give the oracle's bytes, values, counts and statuses."""
+    if chunk_bytes is None:
+        monkeypatch.delenv("CVEC_PIPE_CHUNK_BYTES", raising=False)
+    else:
+        monkeypatch.setenv("CVEC_PIPE_CHUNK_BYTES", chunk_bytes)
+    for tname in ("u32", "u64", "f32"):
+        rng = np.random.default_rng(77 + ET[tname])
+        vals, eo = _random_vectors(rng, tname, 300, max_len=2500)
+        blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+        got = cv.encode_host(tname, vals, eo)
+        assert np.array_equal(got.byte_off, bo) and np.array_equal(got.blob, blob)
+        dec, out_off, st = cv.decode_host(got, add_const=None if tname == "u64" else 3, return_status=True)
+        want, wst, rc = oracle.batch_decode(ET[tname], blob, bo, out_off, add_base=None if tname == "u64" else 3)
+        assert rc == 0 and not st.any() and np.array_equal(_bits(dec), _bits(want))
+        nz = vals[vals != 0]
+        for p in (0, nz[3], [nz[1], 0, nz[5]]):
+            total, per = cv.filter_count_host(got, p, per_vector=True)
+            wtotal, wper, _, rc = oracle.batch_filter_count(ET[tname], blob, bo, p)
+            assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+    # a damaged vector in the middle: its status and the partial counts travel through the chunking
+    rng = np.random.default_rng(5)
+    vals, eo = _random_vectors(rng, "u32", 40, max_len=1200)
+    blob, bo = oracle.batch_encode(ET["u32"], vals, eo)
+    bad = blob.copy()
+    v = 17
+    bad[int(bo[v]) + 16] = 0x09                      # first section type byte of vector 17: not a section type
+    total, per, st = cv.filter_count_host(cv.EncodedBatch("u32", bad, bo), 0, per_vector=True, return_status=True)
+    wtotal, wper, wst, rc = oracle.batch_filter_count(ET["u32"], bad, bo, 0)
+    assert total == wtotal and np.array_equal(per, wper) and np.array_equal(st, wst) and st[v] != 0
+    # pinned caller buffers take the same path
+    pv, pe = cv.hostpath.pin(vals), cv.hostpath.pin(eo)
+    assert np.array_equal(cv.encode_host("u32", pv, pe).blob, blob)
+    # empty batch
+    e = cv.encode_host("u32", np.zeros(0, dtype=np.uint32), np.zeros(1, dtype=np.uint64))
+    assert e.n_vectors == 0 and e.blob.size == 0 and cv.filter_count_host(e, 1) == 0
 
 
 def test_full_size_properties_cfg5_shape(cv):
