@@ -57,7 +57,7 @@ class MaskColumn(C.Structure):
 
 
 MAX_COLUMNS = 16
-STREAM_U64_DELTA, STREAM_F64_XOR = 1, 2
+STREAM_U64_DELTA, STREAM_F64_XOR, STREAM_U64_PLAIN = 1, 2, 3
 
 # Every symbol include/cvec.h declares, with its signature.
 SIGNATURES = {
@@ -92,6 +92,11 @@ SIGNATURES = {
     "cvec_stream_unpack_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                            C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.c_void_p]),
+    "cvec_hist_max_packed_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32]),
+    "cvec_hist_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint32]),
+    "cvec_hist_delta_diff_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64,
+                                             C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_max_encoded_bytes": (C.c_size_t, [C.c_int32, C.c_uint64, C.c_uint64]),
     "cvec_encode_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
     "cvec_encode_dev": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,

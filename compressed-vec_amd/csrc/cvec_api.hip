@@ -43,6 +43,12 @@ size_t stream_pack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total);
 hipError_t launch_stream_pack(int kind, const uint64_t *d_values, const uint64_t *d_elem_off, uint64_t n,
                               uint64_t n_values_total, uint8_t *d_bytes, uint64_t *d_byte_off, int32_t *d_status,
                               uint64_t *d_result, void *d_ws, hipStream_t stream);
+// cvec_stream.hip: histograms
+size_t hist_workspace_bytes(uint64_t n_hist, uint32_t num_buckets);
+hipError_t launch_hist_delta_diff(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                  const uint64_t *d_series_off, uint64_t n_series, uint64_t n_hist, uint32_t num_buckets,
+                                  uint8_t *d_out, uint64_t *d_out_off, uint32_t *d_dropped, int32_t *d_status,
+                                  uint64_t *d_result, void *d_ws, hipStream_t stream);
 // cvec_encode.hip
 size_t encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
 hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
@@ -523,7 +529,9 @@ cvec_status cvec_match_positions_dev(const cvec_mask_column *col, uint64_t n_vec
     return CVEC_OK;
 }
 
-static inline bool stream_kind_ok(int32_t k) { return k == CVEC_STREAM_U64_DELTA || k == CVEC_STREAM_F64_XOR; }
+static inline bool stream_kind_ok(int32_t k) {
+    return k == CVEC_STREAM_U64_DELTA || k == CVEC_STREAM_F64_XOR || k == CVEC_STREAM_U64_PLAIN;
+}
 
 size_t cvec_stream_max_packed_bytes(int32_t kind, uint64_t n_streams, uint64_t n_values_total) {
     // every octet at most 2 + 64 bytes; a stream of n values has ceil(n/8) octets; XOR streams add 8 raw bytes
@@ -564,6 +572,30 @@ cvec_status cvec_stream_unpack_dev(int32_t kind, const uint8_t *d_bytes, const u
     hipError_t e = launch_stream_unpack(kind, d_bytes, d_byte_off, n_bytes, d_elem_off, n_streams, n_values_total, d_out,
                                         d_status, d_result, d_workspace, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_stream_unpack_dev");
+    return CVEC_OK;
+}
+
+size_t cvec_hist_max_packed_bytes(uint64_t n_hist, uint32_t num_buckets) {
+    return (size_t)n_hist * (((size_t)num_buckets + 7) / 8 + 1) * 66 + 16;
+}
+
+size_t cvec_hist_workspace_bytes(uint64_t n_hist, uint32_t num_buckets) { return hist_workspace_bytes(n_hist, num_buckets); }
+
+cvec_status cvec_hist_delta_diff_dev(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                     const uint64_t *d_series_off, uint64_t n_series, uint64_t n_hist,
+                                     uint32_t num_buckets, uint8_t *d_out, size_t out_cap, uint64_t *d_out_off,
+                                     uint32_t *d_dropped, int32_t *d_status, uint64_t *d_result, void *d_workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!d_byte_off || !d_series_off || !d_out || !d_out_off || !d_dropped || !d_status || !d_result || !d_workspace ||
+        (n_bytes && !d_bytes))
+        return CVEC_ERR_BAD_ARGUMENT;
+    if (num_buckets > 0xffff) return CVEC_ERR_BAD_ARGUMENT; // BinHistogramHeader.num_buckets is a u16 (src/histogram.rs:21)
+    if ((((uintptr_t)d_bytes) & 15) != 0 || (((uintptr_t)d_out) & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
+    if (out_cap < cvec_hist_max_packed_bytes(n_hist, num_buckets)) return CVEC_NOT_ENOUGH_SPACE;
+    if (workspace_bytes < hist_workspace_bytes(n_hist, num_buckets)) return CVEC_ERR_WORKSPACE;
+    hipError_t e = launch_hist_delta_diff(d_bytes, d_byte_off, n_bytes, d_series_off, n_series, n_hist, num_buckets, d_out,
+                                          d_out_off, d_dropped, d_status, d_result, d_workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_hist_delta_diff_dev");
     return CVEC_OK;
 }
 

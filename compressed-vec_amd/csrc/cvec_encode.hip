@@ -529,6 +529,8 @@ __device__ inline void load_stream_block(const uint64_t *__restrict__ v, uint64_
         if (idx < npacked) {
             if (KIND == CVEC_STREAM_F64_XOR) {
                 y = v[idx + 1] ^ v[idx];
+            } else if (KIND == CVEC_STREAM_U64_PLAIN) {
+                y = v[idx];
             } else {
                 const uint64_t cur = v[idx], prev = idx ? v[idx - 1] : 0;
                 y = cur >= prev ? cur - prev : 0;
@@ -683,8 +685,161 @@ hipError_t launch_stream_pack(int kind, const uint64_t *d_values, const uint64_t
     if (kind == CVEC_STREAM_F64_XOR)
         return stream_pack_t<CVEC_STREAM_F64_XOR>(d_values, d_elem_off, n, n_values_total, d_bytes, d_byte_off, d_status,
                                                   d_result, d_ws, stream);
+    if (kind == CVEC_STREAM_U64_PLAIN)
+        return stream_pack_t<CVEC_STREAM_U64_PLAIN>(d_values, d_elem_off, n, n_values_total, d_bytes, d_byte_off, d_status,
+                                                    d_result, d_ws, stream);
     return stream_pack_t<CVEC_STREAM_U64_DELTA>(d_values, d_elem_off, n, n_values_total, d_bytes, d_byte_off, d_status,
                                                 d_result, d_ws, stream);
+}
+
+// ---- histograms: DeltaDiffPackSink (reference src/histogram.rs:92-171) -----------------------------
+// A histogram arrives as a NibblePack stream of num_buckets values (bucket-to-bucket deltas).  The
+// sink re-packs it as the difference to the previous histogram of the same series, bucket by bucket;
+// a bucket that fell below its predecessor is passed through unchanged and flags the histogram
+// (:138-143).  Because last_hist_deltas is simply the previous histogram's values (:146-148) there is
+// no chain: every histogram is independent given its predecessor's unpacked values.
+// `raw` holds the unpacked values in blocks of 256: histogram h, value i at raw[(h * in_blocks) * 256 + i].
+// finish() packs the last octet a second time (:117-122: `i` is already past it); that octet is part
+// of the reference's output and is reproduced: value index i >= 8 * noct stands for i - 8.
+
+struct HistShape {
+    uint32_t num_buckets;
+    uint32_t noct;       // octets of one histogram: ceil(num_buckets / 8)
+    uint32_t in_blocks;  // 256-value blocks per unpacked histogram
+    uint32_t out_blocks; // 32-octet blocks per re-packed histogram (noct + 1 octets)
+};
+
+// One lane per series: a histogram is usable when it and every earlier histogram of its series
+// unpacked (the reference's sink state is undefined after a failed unpack); the first failure's code
+// is handed down the series.  Also marks the first histogram of each series.
+__global__ void k_hist_status(const uint64_t *__restrict__ series_off, uint64_t n_series, HistShape sh,
+                              const uint32_t *__restrict__ sec_res, int32_t *__restrict__ status,
+                              uint32_t *__restrict__ first, uint32_t *__restrict__ dropped) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    int carried = CVEC_OK;
+    for (uint64_t h = series_off[s]; h < series_off[s + 1]; h++) {
+        int st = status[h];
+        for (uint32_t b = 0; b < sh.in_blocks && st == CVEC_OK; b++) {
+            const uint32_t r = sec_res[h * sh.in_blocks + b];
+            if (r >> 16) st = (int)(r >> 16);
+        }
+        if (carried == CVEC_OK) carried = st;
+        status[h] = carried;
+        first[h] = h == series_off[s];
+        dropped[h] = 0;
+    }
+}
+
+// Values idx0 + 4 * lane + 0..3 of re-packed histogram h; `low` collects "a bucket fell".
+__device__ inline void load_hist_block(const uint64_t *__restrict__ raw, uint64_t h, bool is_first, bool ok, HistShape sh,
+                                       uint32_t idx0, int lane, uint64_t x[4], bool &low) {
+    const uint64_t *cur = raw + h * sh.in_blocks * FIXED_LEN;
+    const uint64_t *prev = cur - (uint64_t)sh.in_blocks * FIXED_LEN; // only read when !is_first
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t idx = idx0 + 4 * lane + i;
+        uint64_t y = 0;
+        if (ok && idx < 8 * (sh.noct + 1)) {
+            if (idx >= 8 * sh.noct) idx -= 8; // the octet that finish() repeats
+            if (idx < sh.num_buckets) {
+                const uint64_t c = cur[idx], p = is_first ? 0 : prev[idx];
+                if (c < p) { low = true; y = c; } else y = c - p;
+            }
+        }
+        x[i] = y;
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void k_hist_sizes(const uint64_t *__restrict__ raw, uint64_t n_hist, HistShape sh,
+                                                             const int32_t *__restrict__ status,
+                                                             const uint32_t *__restrict__ first,
+                                                             uint64_t *__restrict__ blk_size,
+                                                             uint32_t *__restrict__ dropped) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t blk = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + (threadIdx.x >> 6);
+    if (blk >= n_hist * sh.out_blocks) return;
+    const uint64_t h = blk / sh.out_blocks;
+    const uint32_t j = (uint32_t)(blk % sh.out_blocks);
+    const bool ok = status[h] == CVEC_OK;
+    const uint32_t left = sh.noct + 1 - 32 * j, noct = ok ? (left < 32 ? left : 32) : 0;
+    uint64_t x[4];
+    bool low = false;
+    load_hist_block(raw, h, first[h] != 0, ok, sh, j * FIXED_LEN, lane, x, low);
+    const uint32_t sz = (uint32_t)(lane >> 1) < noct ? octet_info<uint64_t>(x, lane).size : 0u;
+    const uint32_t total = pair_scan_total(sz).total;
+    if (lane == 0) blk_size[blk] = total;
+    if (__ballot(low) && lane == 0) atomicOr(&dropped[h], 1u);
+}
+
+__global__ void k_hist_offsets(uint64_t n_hist, HistShape sh, const uint64_t *__restrict__ blk_scan,
+                               const int32_t *__restrict__ status, uint64_t *__restrict__ out_off,
+                               uint64_t *__restrict__ result) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_hist) return;
+    out_off[h] = blk_scan[h * sh.out_blocks];
+    if (h == n_hist) { result[0] = out_off[h]; return; }
+    const int st = status[h];
+    if (st) { atomicAdd((unsigned long long *)&result[1], 1ull); atomicMax((unsigned long long *)&result[2], (unsigned long long)st); }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void k_hist_emit(const uint64_t *__restrict__ raw, uint64_t n_hist, HistShape sh,
+                                                            const int32_t *__restrict__ status,
+                                                            const uint32_t *__restrict__ first,
+                                                            const uint64_t *__restrict__ blk_scan,
+                                                            uint8_t *__restrict__ bytes) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_buf[ENC_THREADS / 64][EncBuf<8>::DWORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t blk = (uint64_t)blockIdx.x * (ENC_THREADS / 64) + wave;
+    if (blk >= n_hist * sh.out_blocks) return;
+    const uint64_t h = blk / sh.out_blocks;
+    const uint32_t j = (uint32_t)(blk % sh.out_blocks);
+    if (status[h] != CVEC_OK) return;
+    const uint32_t left = sh.noct + 1 - 32 * j, noct = left < 32 ? left : 32;
+    const uint64_t dst_off = blk_scan[blk];
+    const uint32_t size = (uint32_t)(blk_scan[blk + 1] - dst_off);
+    uint64_t x[4];
+    bool low = false;
+    load_hist_block(raw, h, first[h] != 0, true, sh, j * FIXED_LEN, lane, x, low);
+    uint32_t *buf = s_buf[wave];
+    const uint32_t phase = (uint32_t)(dst_off & 15);
+    const uint32_t npieces = (phase + size + 15) >> 4;
+    for (uint32_t d = lane; d < npieces; d += 64) ((uint4 *)buf)[d] = make_uint4(0, 0, 0, 0);
+    image_octets<uint64_t>(x, lane, buf, phase, 0, noct);
+    image_copy_out(buf, phase, size, bytes + dst_off, lane);
+}
+
+HistShape hist_shape(uint32_t num_buckets) {
+    HistShape sh;
+    sh.num_buckets = num_buckets;
+    sh.noct = (num_buckets + 7) / 8;
+    sh.in_blocks = (num_buckets + FIXED_LEN - 1) / FIXED_LEN;
+    sh.out_blocks = sh.noct ? (sh.noct + 1 + 31) / 32 : 0;
+    return sh;
+}
+// workspace of the re-pack half: blk_size, blk_scan, scan scratch
+size_t hist_pack_workspace_bytes(uint64_t n_hist, uint32_t num_buckets) {
+    const uint64_t nb = n_hist * hist_shape(num_buckets).out_blocks;
+    return ((nb + 1) * 8 + 255) / 256 * 256 * 2 + (scan_scratch_words(nb) * 8 + 255) / 256 * 256;
+}
+hipError_t launch_hist_pack(const uint64_t *raw, const uint32_t *sec_res, const uint64_t *d_series_off, uint64_t n_series,
+                            uint64_t n_hist, uint32_t num_buckets, int32_t *d_status, uint32_t *d_first,
+                            uint8_t *d_out, uint64_t *d_out_off, uint32_t *d_dropped, uint64_t *d_result, void *d_ws,
+                            hipStream_t stream) {
+    const HistShape sh = hist_shape(num_buckets);
+    const uint64_t nb = n_hist * sh.out_blocks;
+    uint8_t *b = (uint8_t *)d_ws;
+    const size_t step = ((nb + 1) * 8 + 255) / 256 * 256;
+    uint64_t *blk_size = (uint64_t *)b, *blk_scan = (uint64_t *)(b + step), *scratch = (uint64_t *)(b + 2 * step);
+    if (n_series) k_hist_status<<<(uint32_t)((n_series + 255) / 256), 256, 0, stream>>>(d_series_off, n_series, sh, sec_res,
+                                                                                     d_status, d_first, d_dropped);
+    const uint32_t gb = (uint32_t)((nb + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
+    if (nb) k_hist_sizes<<<gb, ENC_THREADS, 0, stream>>>(raw, n_hist, sh, d_status, d_first, blk_size, d_dropped);
+    hipError_t e = launch_exclusive_scan(blk_size, nb, blk_scan, scratch, stream);
+    if (e != hipSuccess) return e;
+    k_hist_offsets<<<(uint32_t)((n_hist + 256) / 256), 256, 0, stream>>>(n_hist, sh, blk_scan, d_status, d_out_off, d_result);
+    if (nb) k_hist_emit<<<gb, ENC_THREADS, 0, stream>>>(raw, n_hist, sh, d_status, d_first, blk_scan, d_out);
+    return hipGetLastError();
 }
 
 // ---- launcher --------------------------------------------------------------------------------------------

@@ -165,9 +165,11 @@ __global__ void k_fill_skip(const uint64_t *__restrict__ n_real, uint64_t fill_o
     if (b < max_blocks && b >= *n_real) desc[b] = desc_pack(fill_off, 0, K_SKIP);
 }
 
-// Combine of the stream's running state: wrapping sum (DeltaSink) or XOR (DoubleXorSink).
+// Combine of the stream's running state: wrapping sum (DeltaSink), XOR (DoubleXorSink) or none.
 template <int KIND> __device__ inline uint64_t comb(uint64_t a, uint64_t b) {
-    return KIND == CVEC_STREAM_F64_XOR ? a ^ b : a + b;
+    // plain streams have no running state: "keep the right operand" is associative, so they run
+    // through the same scan and come out unchanged
+    return KIND == CVEC_STREAM_F64_XOR ? a ^ b : KIND == CVEC_STREAM_U64_PLAIN ? b : a + b;
 }
 
 // Inclusive wave scan of one value per lane.
@@ -334,8 +336,73 @@ hipError_t launch_stream_unpack(int kind, const uint8_t *d_bytes, const uint64_t
     if (kind == CVEC_STREAM_F64_XOR)
         return unpack_t<CVEC_STREAM_F64_XOR>(d_bytes, d_byte_off, n_bytes, d_elem_off, n, n_values_total, d_out, d_status,
                                              d_result, d_ws, stream);
+    if (kind == CVEC_STREAM_U64_PLAIN)
+        return unpack_t<CVEC_STREAM_U64_PLAIN>(d_bytes, d_byte_off, n_bytes, d_elem_off, n, n_values_total, d_out, d_status,
+                                               d_result, d_ws, stream);
     return unpack_t<CVEC_STREAM_U64_DELTA>(d_bytes, d_byte_off, n_bytes, d_elem_off, n, n_values_total, d_out, d_status,
                                            d_result, d_ws, stream);
+}
+
+// ---- histograms: DeltaDiffPackSink for batches of histogram series ---------------------------------
+// (reference src/histogram.rs:92-171).  The histograms are plain NibblePack streams of num_buckets
+// values each; they are unpacked like any other stream batch (index -> K_RAW blocks through the
+// section kernel), then cvec_encode.hip re-packs every histogram as the difference to its
+// predecessor in the series.
+size_t hist_pack_workspace_bytes(uint64_t n_hist, uint32_t num_buckets);
+hipError_t launch_hist_pack(const uint64_t *raw, const uint32_t *sec_res, const uint64_t *d_series_off, uint64_t n_series,
+                            uint64_t n_hist, uint32_t num_buckets, int32_t *d_status, uint32_t *d_first, uint8_t *d_out,
+                            uint64_t *d_out_off, uint32_t *d_dropped, uint64_t *d_result, void *d_ws, hipStream_t stream);
+
+__global__ void k_hist_elem_off(uint64_t n_hist, uint32_t num_buckets, uint64_t *__restrict__ elem_off) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h <= n_hist) elem_off[h] = h * num_buckets;
+}
+
+struct HistWs {
+    StreamUnpackWs u;
+    uint64_t *elem_off;
+    uint32_t *first;
+    void *pack;
+    size_t total;
+};
+static HistWs carve_hist(void *base, uint64_t n_hist, uint32_t num_buckets) {
+    HistWs w;
+    const uint64_t total_values = n_hist * num_buckets;
+    w.u = carve_unpack(base, n_hist, max_blocks_of(n_hist, total_values));
+    uint8_t *b = (uint8_t *)base;
+    size_t off = w.u.total;
+    w.elem_off = (uint64_t *)(b + off); off += al256((n_hist + 1) * 8);
+    w.first = (uint32_t *)(b + off); off += al256((n_hist + 1) * 4);
+    w.pack = b + off; off += hist_pack_workspace_bytes(n_hist, num_buckets);
+    w.total = off;
+    return w;
+}
+size_t hist_workspace_bytes(uint64_t n_hist, uint32_t num_buckets) { return carve_hist(nullptr, n_hist, num_buckets).total; }
+
+hipError_t launch_hist_delta_diff(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                  const uint64_t *d_series_off, uint64_t n_series, uint64_t n_hist, uint32_t num_buckets,
+                                  uint8_t *d_out, uint64_t *d_out_off, uint32_t *d_dropped, int32_t *d_status,
+                                  uint64_t *d_result, void *d_ws, hipStream_t stream) {
+    constexpr int KIND = CVEC_STREAM_U64_PLAIN;
+    HistWs w = carve_hist(d_ws, n_hist, num_buckets);
+    const uint64_t maxb = max_blocks_of(n_hist, n_hist * num_buckets);
+    hipError_t e = hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
+    if (e != hipSuccess) return e;
+    const uint32_t g = (uint32_t)((n_hist + 256) / 256);
+    k_hist_elem_off<<<g, 256, 0, stream>>>(n_hist, num_buckets, w.elem_off);
+    if (n_hist) {
+        k_stream_nblk<<<g, 256, 0, stream>>>(KIND, w.elem_off, n_hist, w.u.nblk);
+        e = launch_exclusive_scan(w.u.nblk, n_hist, w.u.blk_base, w.u.scan_scratch, stream);
+        if (e != hipSuccess) return e;
+        k_stream_index<<<(uint32_t)((n_hist + IDX_WAVES - 1) / IDX_WAVES), 64 * IDX_WAVES, 0, stream>>>(
+            KIND, d_bytes, d_byte_off, w.elem_off, w.u.blk_base, n_hist, (n_bytes + 15) & ~15ull, w.u.desc, w.u.blk_stream,
+            d_status);
+        k_fill_skip<<<(uint32_t)((maxb + 255) / 256), 256, 0, stream>>>(w.u.blk_base + n_hist, n_bytes, w.u.desc, maxb);
+        e = launch_raw_blocks_u64(d_bytes, w.u.desc, maxb, w.u.sec_res, w.u.raw, stream);
+        if (e != hipSuccess) return e;
+    }
+    return launch_hist_pack(w.u.raw, w.u.sec_res, d_series_off, n_series, n_hist, num_buckets, d_status, w.first, d_out,
+                            d_out_off, d_dropped, d_result, w.pack, stream);
 }
 
 } // namespace cvec

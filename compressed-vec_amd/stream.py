@@ -9,7 +9,7 @@ import torch
 from . import _native as N
 from .batch import _ptr, _stream_ptr
 
-KINDS = {"u64_delta": N.STREAM_U64_DELTA, "f64_xor": N.STREAM_F64_XOR}
+KINDS = {"u64_delta": N.STREAM_U64_DELTA, "f64_xor": N.STREAM_F64_XOR, "u64": N.STREAM_U64_PLAIN}
 
 
 def _as_bits(values, kind, device):
@@ -112,6 +112,22 @@ def unpack_f64_xor(buf, num_values):
     """nibblepacking::unpack_f64_xor into a DoubleXorSink (src/nibblepacking.rs:284-325, :392-400)."""
     b = np.frombuffer(bytes(buf), dtype=np.uint8)
     vals, st = unpack_batch(N.STREAM_F64_XOR, b, [0, b.size], [0, num_values])
+    if st[0]:
+        raise N.CodingError(int(st[0]))
+    return vals
+
+
+def pack_u64(values):
+    """nibblepacking::pack_u64 (src/nibblepacking.rs:68-93) of one stream: the values as they are."""
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    blob, _, _ = pack_batch(N.STREAM_U64_PLAIN, v, [0, v.size])
+    return blob.tobytes()
+
+
+def unpack_u64(buf, num_values):
+    """nibblepacking::unpack (src/nibblepacking.rs:364-377) into a plain value sink."""
+    b = np.frombuffer(bytes(buf), dtype=np.uint8)
+    vals, st = unpack_batch(N.STREAM_U64_PLAIN, b, [0, b.size], [0, num_values])
     if st[0]:
         raise N.CodingError(int(st[0]))
     return vals

@@ -193,7 +193,9 @@ cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t 
                             uint64_t *d_sec_base, uint64_t *d_result, void *d_workspace, size_t workspace_bytes,
                             void *stream);
 
-/* ---- legacy NibblePack stream codecs (batches of streams) ------------------------------------- */
+/* ---- legacy NibblePack stream codecs (batches of streams) -------------------------------------
+ * CVEC_STREAM_U64_PLAIN is pack_u64 / unpack themselves (src/nibblepacking.rs:68-93, :364-377):
+ * the values as they are, no delta or XOR. */
 
 /* pack_u64_delta (src/nibblepacking.rs:15-23: deltas clipped at 0, then pack_u64 :68-93) or
  * pack_f64_xor (:29-45: first value raw, then XOR with the predecessor) for n_streams streams;
@@ -201,7 +203,7 @@ cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t 
  * streams back to back into d_bytes (16-byte aligned, capacity >= cvec_stream_max_packed_bytes) and
  * d_byte_off[n_streams+1]; d_result[0] = bytes written.  d_status (nullable): per stream, only
  * InputTooShort for an empty XOR stream (src/nibblepacking.rs:37). */
-enum { CVEC_STREAM_U64_DELTA = 1, CVEC_STREAM_F64_XOR = 2 };
+enum { CVEC_STREAM_U64_DELTA = 1, CVEC_STREAM_F64_XOR = 2, CVEC_STREAM_U64_PLAIN = 3 };
 size_t cvec_stream_max_packed_bytes(int32_t kind, uint64_t n_streams, uint64_t n_values_total);
 size_t cvec_stream_pack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total);
 cvec_status cvec_stream_pack_dev(int32_t kind, const uint64_t *d_values, const uint64_t *d_elem_off,
@@ -219,6 +221,29 @@ cvec_status cvec_stream_unpack_dev(int32_t kind, const uint8_t *d_bytes, const u
                                    const uint64_t *d_elem_off, uint64_t n_streams, uint64_t n_values_total,
                                    uint64_t *d_out, int32_t *d_status, uint64_t *d_result, void *d_workspace,
                                    size_t workspace_bytes, void *stream);
+
+/* ---- histograms ------------------------------------------------------------------------------ */
+
+/* DeltaDiffPackSink (src/histogram.rs:92-171) for batches of histogram series, driven the way the
+ * reference drives it (examples/2d_delta_bench.rs:53-57): for every histogram
+ * unpack(bytes, sink, num_buckets) then sink.finish(), with sink.reset() at the start of a series.
+ * Input: n_hist NibblePack streams of num_buckets u64 each (pack_u64 / pack_u64_delta output:
+ * histogram h is d_bytes[d_byte_off[h] .. d_byte_off[h+1])); series s owns the consecutive
+ * histograms d_series_off[s] .. d_series_off[s+1] (d_series_off[0] = 0, [n_series] = n_hist).
+ * Output: for every histogram the NibblePack stream of its bucket-wise difference to the previous
+ * histogram of the series (to zero for the first); a bucket below its predecessor is passed through
+ * and sets d_dropped[h] (the sink's value_dropped before finish() clears it).  As in the reference,
+ * finish() packs the last octet a second time, so every stream holds ceil(num_buckets/8) + 1 octets.
+ * A histogram that fails to unpack gets its status in d_status[h] and an empty stream, and so does
+ * every later histogram of its series.  d_result[0] = bytes written, [1] = failed histograms.
+ * d_bytes and d_out 16-byte aligned (d_bytes padded as for a batch). */
+size_t cvec_hist_max_packed_bytes(uint64_t n_hist, uint32_t num_buckets);
+size_t cvec_hist_workspace_bytes(uint64_t n_hist, uint32_t num_buckets);
+cvec_status cvec_hist_delta_diff_dev(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
+                                     const uint64_t *d_series_off, uint64_t n_series, uint64_t n_hist,
+                                     uint32_t num_buckets, uint8_t *d_out, size_t out_cap, uint64_t *d_out_off,
+                                     uint32_t *d_dropped, int32_t *d_status, uint64_t *d_result, void *d_workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* ---- host-buffer entry points (what a Rust ffi.rs shim behind the unchanged crate API calls) -- */
 /* The batch is cut into chunks of whole vectors (about 64 MiB; the environment variable

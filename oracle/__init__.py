@@ -55,6 +55,10 @@ def lib():
             "ocv_unpack_u64_delta": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, szp]),
             "ocv_pack_f64_xor": (C.c_int64, [vp, C.c_size_t, vp, C.c_size_t]),
             "ocv_unpack_f64_xor": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, szp]),
+            "ocv_compress_geom_nonincreasing": (C.c_int64, [C.c_uint16, C.c_double, C.c_double, C.c_uint8, vp,
+                                                            C.c_size_t, vp, C.c_size_t]),
+            "ocv_delta_diff_pack": (C.c_int, [vp, C.c_size_t, C.c_size_t, vp, vp, C.c_size_t, szp, C.POINTER(C.c_int),
+                                              szp]),
             "ocv_set_ref_tail_quirk": (None, [C.c_int]),
             "ocv_section_write": (C.c_int64, [C.c_int, vp, vp, C.c_size_t, C.c_size_t]),
             "ocv_section_write_kind": (C.c_int64, [C.c_int, C.c_int, vp, vp, C.c_size_t, C.c_size_t]),
@@ -170,6 +174,38 @@ def unpack_u64_delta(buf, nvalues):
     c = C.c_size_t(0)
     _check(lib().ocv_unpack_u64_delta(_ptr(b), b.size, _ptr(out), nvalues, C.byref(c)))
     return out, c.value
+
+
+def compress_geom_nonincreasing(num_buckets, initial_bucket, multiplier, format_code, values):
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    cap = 21 + 66 * ((v.size + 7) // 8) + 16
+    out = np.zeros(cap, dtype=np.uint8)
+    r = lib().ocv_compress_geom_nonincreasing(num_buckets, initial_bucket, multiplier, format_code, _ptr(v), v.size,
+                                              _ptr(out), cap)
+    if r < 0:
+        raise OracleError(-r)
+    return out[:r].tobytes()
+
+
+class DeltaDiffPackSink:
+    """histogram.rs:92-171 as the reference drives it: feed(packed) = unpack(packed, sink, num_buckets) then
+    finish(); returns (bytes appended by this histogram, value_dropped, bytes consumed)."""
+
+    def __init__(self, num_buckets):
+        self.num_buckets = num_buckets
+        self.last = np.zeros(max(num_buckets, 1), dtype=np.uint64)
+
+    def reset(self):
+        self.last[:] = 0
+
+    def feed(self, packed):
+        b = _bytes_arr(packed)
+        cap = 66 * ((self.num_buckets + 7) // 8 + 1) + 16
+        out = np.zeros(cap, dtype=np.uint8)
+        off, c, dropped = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+        _check(lib().ocv_delta_diff_pack(_ptr(b), b.size, self.num_buckets, _ptr(self.last), _ptr(out), cap,
+                                         C.byref(off), C.byref(dropped), C.byref(c)))
+        return out[:off.value].tobytes(), bool(dropped.value), c.value
 
 
 def pack_f64_xor(vals):

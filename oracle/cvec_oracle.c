@@ -248,6 +248,69 @@ int ocv_unpack_f64_xor(const uint8_t *in, size_t len, double *out, size_t nvalue
     return rc;
 }
 
+/* ---------- histograms (histogram.rs) ---------- */
+
+/* compress_geom_nonincreasing (histogram.rs:55-76): BinHistogramHeader {format_code u8, bucket_def_len
+ * u16 = 18, num_buckets u16} (packed, :16-22), PackedGeometricBuckets {initial_bucket f64, multiplier
+ * f64} (:40-45), then pack_u64 of the values at offset bucket_def_len + 3 = 21 (:75). */
+int64_t ocv_compress_geom_nonincreasing(uint16_t num_buckets, double initial_bucket, double multiplier,
+                                        uint8_t format_code, const uint64_t *values, size_t n_values, uint8_t *out,
+                                        size_t cap) {
+    if (cap < 21) return -OCV_NOT_ENOUGH_SPACE;
+    const uint16_t bucket_def_len = 16 + 2;                       /* :62 */
+    out[0] = format_code;                                         /* :64 */
+    wr_le(out + 1, bucket_def_len, 2);                            /* :65 */
+    wr_le(out + 3, num_buckets, 2);                               /* :66 */
+    uint64_t b;
+    memcpy(&b, &initial_bucket, 8);
+    wr_le(out + 5, b, 8);                                         /* :71 */
+    memcpy(&b, &multiplier, 8);
+    wr_le(out + 13, b, 8);                                        /* :72 */
+    return ocv_pack_u64(values, n_values, out, cap, (size_t)bucket_def_len + 3);
+}
+
+/* DeltaDiffPackSink (histogram.rs:92-171) driven the way examples/2d_delta_bench.rs:53-57 and the
+ * crate's own test (:213-231) drive it: unpack(in, sink, num_buckets) then sink.finish().
+ * `last` is last_hist_deltas (num_buckets values, the caller zeroes it where the reference calls
+ * reset()).  The packed differences are appended to out at *out_off.  *value_dropped is the flag as
+ * it stands after the unpack, before finish() clears it (:124).  finish() packs the last octet a
+ * second time whenever at least one octet was processed (:117-122: `i` is already past it, so the
+ * zero-fill loop is empty and pack_array still holds the last octet); that duplicate is reproduced. */
+int ocv_delta_diff_pack(const uint8_t *in, size_t len, size_t num_buckets, uint64_t *last, uint8_t *out, size_t cap,
+                        size_t *out_off, int *value_dropped, size_t *consumed) {
+    size_t pos = 0, i = 0;
+    int dropped = 0;
+    uint64_t pack_array[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t off = (int64_t)*out_off;
+    for (long left = (long)num_buckets; left > 0; left -= 8) {    /* unpack, nibblepacking.rs:370-375 */
+        uint64_t data[8];
+        size_t c = 0;
+        int rc = ocv_nibble_unpack8(in + pos, len - pos, data, &c);
+        if (rc) return rc;
+        pos += c;
+        const size_t looplen = i + 8 <= num_buckets ? 8 : num_buckets - i;     /* :132 */
+        for (size_t n = 0; n < looplen; n++) {                    /* :133-144 */
+            const uint64_t lastv = last[i + n];
+            if (data[n] < lastv) { dropped = 1; pack_array[n] = data[n]; }
+            else pack_array[n] = data[n] - lastv;
+        }
+        for (size_t n = 0; n < looplen; n++) last[i + n] = data[n];           /* :146-148 */
+        for (size_t n = looplen; n < 8; n++) pack_array[n] = 0;               /* :150-152 */
+        off = ocv_nibble_pack8(pack_array, out, cap, (size_t)off);            /* :153 */
+        if (off < 0) return (int)-off;
+        i += 8;
+    }
+    if (value_dropped) *value_dropped = dropped;
+    if (i != 0) {                                                 /* finish, :115-125 */
+        for (size_t j = i; j < 8; j++) pack_array[j] = 0;
+        off = ocv_nibble_pack8(pack_array, out, cap, (size_t)off);
+        if (off < 0) return (int)-off;
+    }
+    *out_off = (size_t)off;
+    if (consumed) *consumed = pos;
+    return OCV_OK;
+}
+
 /* ---------- L2: sinks (sink.rs:135-320, filter.rs:53-107) ---------- */
 
 typedef struct sink sink;

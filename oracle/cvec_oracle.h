@@ -76,6 +76,14 @@ int ocv_unpack_u64_delta(const uint8_t *in, size_t len, uint64_t *out, size_t nv
 int64_t ocv_pack_f64_xor(const double *vals, size_t n, uint8_t *out, size_t cap);
 int ocv_unpack_f64_xor(const uint8_t *in, size_t len, double *out, size_t nvalues, size_t *consumed);
 
+/* Histograms: compress_geom_nonincreasing (histogram.rs:55-76) and DeltaDiffPackSink (:92-171) fed by
+ * unpack(in, sink, num_buckets) + finish().  `last` is the sink's last_hist_deltas. */
+int64_t ocv_compress_geom_nonincreasing(uint16_t num_buckets, double initial_bucket, double multiplier,
+                                        uint8_t format_code, const uint64_t *values, size_t n_values, uint8_t *out,
+                                        size_t cap);
+int ocv_delta_diff_pack(const uint8_t *in, size_t len, size_t num_buckets, uint64_t *last, uint8_t *out, size_t cap,
+                        size_t *out_off, int *value_dropped, size_t *consumed);
+
 void ocv_set_ref_tail_quirk(int on);
 
 /* ---- L3: 256-element sections --------------------------------------------------------- */

@@ -447,6 +447,62 @@ def test_legacy_stream_codecs_vs_oracle(cv, oracle):
     assert list(cv.stream.unpack_u64_delta(enc, 12)) == [0, 1000, 1001, 1002, 1003, 2005, 2010, 3034, 4045, 5056, 6067, 7078]
 
 
+def test_histogram_delta_diff_pack_vs_oracle(cv, oracle, kats):
+    """DeltaDiffPackSink (src/histogram.rs:92-171) over series of histograms, and
+    compress_geom_nonincreasing (:55-76), against the oracle; the reference's own test data first."""
+    hist = cv.histogram
+    d = kats["histogram"]["delta_diffpack"]
+    inputs = [np.array(x, dtype=np.uint64) for x in d["inputs"]]
+    sink, osink = hist.DeltaDiffPackSink(12), oracle.DeltaDiffPackSink(12)
+    for inp in inputs:
+        packed = oracle.pack_u64_delta(inp)
+        want, wdrop, _ = osink.feed(packed)
+        assert sink.feed(packed) == want and sink.value_dropped == wdrop
+    assert hist.compress_geom_nonincreasing(64, 2.0, 2.0, hist.FORMAT_GEOMETRIC_DELTA, inputs[1]) == \
+        oracle.compress_geom_nonincreasing(64, 2.0, 2.0, 1, inputs[1])
+    assert cv.stream.pack_u64(inputs[2]) == oracle.pack_u64(inputs[2])
+    assert np.array_equal(cv.stream.unpack_u64(oracle.pack_u64(inputs[2]), 12), inputs[2])
+    rng = np.random.default_rng(99)
+    for nb in (1, 7, 8, 64, 247, 248, 256, 300, 700):
+        # series of different lengths (one empty), buckets that grow, stall and sometimes reset
+        lens = [5, 0, 1, 9, 3]
+        series_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        packed, want_out, want_drop = [], [], []
+        for ln in lens:
+            osink = oracle.DeltaDiffPackSink(nb)
+            counts = np.zeros(nb, dtype=np.uint64)
+            for t in range(ln):
+                counts = counts + rng.integers(0, 1 << int(rng.integers(1, 40)), nb).astype(np.uint64) * (rng.random(nb) < 0.6)
+                if rng.random() < 0.25:
+                    counts[rng.integers(0, nb)] = 0                       # a counter reset
+                deltas = np.diff(np.concatenate([[0], np.sort(counts)])).astype(np.uint64)
+                if rng.random() < 0.3:
+                    deltas = counts                                       # not increasing bucket to bucket
+                p = oracle.pack_u64(deltas)
+                packed.append(p)
+                o, dr, used = osink.feed(p)
+                assert used == len(p)
+                want_out.append(o)
+                want_drop.append(dr)
+        off = np.concatenate([[0], np.cumsum([len(p) for p in packed])]).astype(np.uint64)
+        blob = np.frombuffer(b"".join(packed), dtype=np.uint8)
+        out, oo, dropped, st = hist.delta_diff_batch(blob, off, series_off, nb)
+        assert not st.any()
+        assert [out[int(oo[h]):int(oo[h + 1])].tobytes() for h in range(len(packed))] == want_out
+        assert list(dropped) == want_drop
+    # a histogram cut short fails, and so do the later ones of its series; other series are untouched
+    nb = 64
+    good = [oracle.pack_u64(rng.integers(1, 1 << 20, nb).astype(np.uint64)) for _ in range(6)]
+    cut = list(good)
+    cut[1] = good[1][:len(good[1]) - 9]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in cut])]).astype(np.uint64)
+    out, oo, dropped, st = hist.delta_diff_batch(np.frombuffer(b"".join(cut), dtype=np.uint8), off, [0, 3, 6], nb)
+    assert st[0] == 0 and st[1] != 0 and st[2] == st[1] and not st[3:].any()
+    assert oo[2] == oo[1] and oo[3] == oo[2]
+    osink = oracle.DeltaDiffPackSink(nb)
+    assert [out[int(oo[h]):int(oo[h + 1])].tobytes() for h in (3, 4, 5)] == [osink.feed(good[h])[0] for h in (3, 4, 5)]
+
+
 @pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
 def test_large_ragged_batch_vs_oracle(cv, oracle, tname):
     """Tens of thousands of sections: every wave of the section kernel runs many chunks, chunk boundaries

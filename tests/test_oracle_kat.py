@@ -454,3 +454,33 @@ def test_multi_vector_filter(oracle):
     want = int(((a == 3) & (b == 2)).sum())
     assert oracle.multi_filter_count(oracle.U32, [va, vb], [3, 2]) == want
     assert oracle.multi_filter_count(oracle.U32, [vb, va], [2, 3]) == want
+
+
+def test_histogram_header_and_delta_diffpack_sink(oracle, kats):
+    """src/histogram.rs:175-194 (header bytes) and :196-238 (DeltaDiffPackSink over three histograms)."""
+    h = kats["histogram"]["header_layout"]
+    got = oracle.compress_geom_nonincreasing(h["num_buckets"], 2.0, 2.0, h["format_code"], [])
+    # the test's header has bucket_def_len 2; compress_geom_nonincreasing always writes 16 + 2 (:62)
+    assert got[0] == h["expected"][0] and list(got[3:5]) == h["expected"][3:5] and list(got[1:3]) == [18, 0]
+    assert len(got) == 21
+    d = kats["histogram"]["delta_diffpack"]
+    inputs = [np.array(x, dtype=np.uint64) for x in d["inputs"]]
+    n = inputs[0].size
+    sink = oracle.DeltaDiffPackSink(n)
+    for i, inp in enumerate(inputs):
+        packed = oracle.pack_u64_delta(inp)
+        out, dropped, consumed = sink.feed(packed)
+        assert not dropped and consumed == len(packed)
+        vals, used = oracle.unpack_u64_delta(out, n)
+        want = inp if i == 0 else inp - inputs[i - 1]
+        assert np.array_equal(vals[:n], want)
+        # finish() packs the last octet twice: the stream holds one octet more than the values need
+        assert used < len(out)
+        again, _ = oracle.unpack_u64(out[used:], 8)
+        raw, _ = oracle.unpack_u64(out, n)
+        assert np.array_equal(again[:8], raw[8:16])
+    # a bucket that falls below its predecessor is passed through and flagged
+    low = inputs[2].copy()
+    low[3] = 5
+    out, dropped, _ = sink.feed(oracle.pack_u64_delta(low))
+    assert dropped
