@@ -3,7 +3,7 @@ the C ABI of include/cvec.h, with the reference crate's API names on top (see sr
 the reference for the list this mirrors)."""
 from ._native import (CodingError, F32, U32, U64, LIB_PATH, lib)
 from .batch import (DeviceBatch, EncodedBatch, FilteredColumn, encode_batch, encode_device, etype_of, make_pred,
-                    multi_filter_count)
+                    multi_filter, multi_filter_count)
 from .filter import EqualsSink, MultiVectorFilter, OneOfSink, VectorFilter, count_hits, match_positions
 from . import stream
 from . import hostpath
@@ -12,7 +12,7 @@ from .hostpath import decode_host, encode_host, filter_count_host
 from .sink import AddConstSink, Section256Sink, VecSink
 from .vector import (VectorAppender, VectorF32XorAppender, VectorReader, VectorU32Appender, VectorU64Appender)
 
-__all__ = ["hostpath", "stream", "histogram", "decode_host", "encode_host", "filter_count_host", "MultiVectorFilter", "FilteredColumn", "multi_filter_count", "CodingError", "U32", "U64", "F32", "DeviceBatch", "EncodedBatch", "encode_batch", "encode_device",
+__all__ = ["hostpath", "stream", "histogram", "decode_host", "encode_host", "filter_count_host", "MultiVectorFilter", "FilteredColumn", "multi_filter", "multi_filter_count", "CodingError", "U32", "U64", "F32", "DeviceBatch", "EncodedBatch", "encode_batch", "encode_device",
            "EqualsSink", "OneOfSink", "VectorFilter", "count_hits", "match_positions", "AddConstSink",
            "Section256Sink", "VecSink", "VectorAppender", "VectorF32XorAppender", "VectorReader",
            "VectorU32Appender", "VectorU64Appender", "etype_of", "make_pred", "lib", "LIB_PATH"]

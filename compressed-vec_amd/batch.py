@@ -173,15 +173,17 @@ class DeviceBatch:
         return raw.view(np.uint32)
 
     # -- operations -------------------------------------------------------------------------------------
-    def filter_count_async(self, pred, per_vector=None, status=None, masks=None, result=None):
+    def filter_count_async(self, pred, per_vector=None, status=None, masks=None, result=None, gate=None):
         """Enqueues decode+filter+count on the current stream; returns the device result tensor
-        (int64[4]: total, failed vectors, max status, reserved)."""
+        (int64[4]: total, failed vectors, max status, reserved).  `gate`: masks of an earlier pass over
+        a batch with the same section layout; sections whose gate mask is empty are not decoded."""
         p = pred if isinstance(pred, N.Pred) else make_pred(self.etype, pred)
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
         with torch.cuda.device(self.device):
-            N.check(N.lib().cvec_filter_count_dev(C.byref(self.view), C.byref(p), _ptr(res), _ptr(per_vector),
-                                                  _ptr(status), _ptr(masks), _ptr(ws), ws.numel(), _stream_ptr()))
+            N.check(N.lib().cvec_filter_count_gated_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
+                                                        _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
+                                                        ws.numel(), _stream_ptr()))
         return res
 
     def filter_count(self, pred, per_vector=False, return_status=False, return_masks=False):
@@ -200,11 +202,17 @@ class DeviceBatch:
             out.append(mk.cpu().numpy())
         return out[0] if len(out) == 1 else tuple(out)
 
-    def filter_masks(self, pred):
+    def filter_masks(self, pred, gate=None):
         """Runs the filter pass and keeps its per-section masks on the device: returns a FilteredColumn
-        (masks, number of sections every vector yielded) for multi_filter_count / match_positions."""
+        (masks, number of sections every vector yielded) for multi_filter_count / match_positions.
+        `gate`: a FilteredColumn over a batch with the same section layout (the previous column of a
+        MultiVectorFilter); sections it left without a match are skipped (src/filter.rs:277-282)."""
         masks = torch.zeros(self.n_sections * 32, dtype=torch.uint8, device=self.device)
-        res = self.filter_count_async(pred, masks=masks)
+        g = None
+        if gate is not None and gate.batch.n_sections == self.n_sections and \
+                torch.equal(gate.batch.d_sec_base, self.d_sec_base):
+            g = gate.masks
+        res = self.filter_count_async(pred, masks=masks, gate=g)
         valid = torch.empty(max(self.n_vectors, 1), dtype=torch.int32, device=self.device)
         ws = self.workspace()
         with torch.cuda.device(self.device):
@@ -259,6 +267,16 @@ class FilteredColumn:
                                                  _ptr(ws), ws.numel(), _stream_ptr()))
         off = pos_off.cpu().numpy().view(np.uint64)
         return pos[:int(off[-1])].cpu().numpy().view(np.uint32), off
+
+
+def multi_filter(batches, preds, per_row=False, return_masks=False):
+    """MultiVectorFilter over whole batches: column c is batches[c] filtered by preds[c]; every column
+    after the first is gated by the masks of the one before it, so sections that an earlier column
+    already ruled out are not decoded (put the most selective column first, src/filter.rs:236-238)."""
+    cols = []
+    for b, p in zip(batches, preds):
+        cols.append(b.filter_masks(p, gate=cols[-1] if cols else None))
+    return multi_filter_count(cols, per_row=per_row, return_masks=return_masks)
 
 
 def multi_filter_count(columns, per_row=False, return_masks=False):

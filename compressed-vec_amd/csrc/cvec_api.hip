@@ -16,7 +16,7 @@ hipError_t launch_sec_base(const uint8_t *d_bytes, const uint64_t *d_byte_off, u
 uint64_t scan_scratch_words(uint64_t n);
 hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
                        uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
-                       int32_t *d_status, uint8_t *d_masks, void *d_out, hipStream_t stream);
+                       int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, hipStream_t stream);
 hipError_t timing_begin(int max_records);
 hipError_t timing_end(float ms[3], int *n_records);
 // cvec_filter_ops.hip
@@ -410,9 +410,17 @@ static cvec_status check_view(const cvec_dbatch_view *b) {
 cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
                                   uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_workspace,
                                   size_t workspace_bytes, void *stream) {
+    return cvec_filter_count_gated_dev(batch, pred, nullptr, d_result, d_per_vector, d_status, d_masks, d_workspace,
+                                       workspace_bytes, stream);
+}
+
+cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const uint8_t *d_gate,
+                                        uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
+                                        uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream) {
     cvec_status st = check_view(batch);
     if (st) return st;
     if (!pred || !d_result || !d_workspace) return CVEC_ERR_BAD_ARGUMENT;
+    if ((((uintptr_t)d_gate) & 15) != 0 || (((uintptr_t)d_masks) & 7) != 0) return CVEC_ERR_BAD_ARGUMENT;
     if (pred->kind != CVEC_PRED_EQ && pred->kind != CVEC_PRED_ONEOF) return CVEC_ERR_BAD_ARGUMENT;
     const uint32_t npred = pred->kind == CVEC_PRED_EQ ? 1u : pred->count;
     if (npred == 0 || npred > CVEC_MAX_PRED_VALUES) return CVEC_ERR_BAD_ARGUMENT;
@@ -432,7 +440,7 @@ cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred
     SinkArgs sa;
     memset(&sa, 0, sizeof(sa));
     hipError_t e = launch_read(0, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, d_per_vector, d_status,
-                               d_masks, nullptr, (hipStream_t)stream);
+                               d_masks, nullptr, d_gate, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_filter_count_dev");
     return CVEC_OK;
 }
@@ -455,7 +463,7 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
         sa.base = batch->etype == CVEC_U64 ? chain->add_const_bits : (chain->add_const_bits & 0xffffffffull);
     }
     hipError_t e = launch_read(1, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status, nullptr,
-                               d_out, (hipStream_t)stream);
+                               d_out, nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_decode_dev");
     return CVEC_OK;
 }

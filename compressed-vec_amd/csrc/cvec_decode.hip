@@ -135,8 +135,9 @@ template <int ETYPE>
 __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes,
                                                const uint64_t *__restrict__ byte_off,
                                                const uint64_t *__restrict__ sec_base, uint64_t n,
-                                               uint64_t padded_bytes, uint64_t *__restrict__ desc,
-                                               int32_t *__restrict__ vstatus, uint64_t *__restrict__ result) {
+                                               uint64_t padded_bytes, const uint8_t *__restrict__ gate,
+                                               uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
+                                               uint64_t *__restrict__ result) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     // One 4-byte load per section header (type byte + 16-bit length), pulled back inside the padded
     // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
@@ -191,7 +192,16 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
             if (e) { st = e; break; }
             if (k >= nslots) { st = CVEC_ERR_SECTION_COUNT; break; }
             const bool legal = ETYPE == CVEC_F32 ? (b0 == K_NULL || b0 == K_CONST || b0 == K_XOR) : (b0 != K_XOR);
-            desc[slot0 + k] = desc_pack(start + pos, (uint32_t)nb, legal ? b0 : K_ILLEGAL);
+            // A section whose gate mask (the 256-bit mask of the same slot of an earlier column) is empty
+            // is only parsed, like MultiVectorFilter's advance() (src/filter.rs:204-209, :279-282).
+            bool off = false;
+            if (gate) {
+                const uint4 *g = (const uint4 *)(gate + 32 * (slot0 + k));
+                const uint4 a = g[0], b = g[1];
+                off = ((a.x | a.y | a.z | a.w) | (b.x | b.y | b.z | b.w)) == 0;
+            }
+            desc[slot0 + k] = off ? desc_pack(start + pos, 0, K_GATED)
+                                  : desc_pack(start + pos, (uint32_t)nb, legal ? b0 : K_ILLEGAL);
             pos += nb;
             k++;
         }
@@ -456,6 +466,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             if constexpr (MODE == MODE_FILTER_MASKS) {
                 // byte k of the section's mask: bits 2q, 2q+1 from each lane of the quad
                 uint32_t bits = zeroes ? (pa.match_zero ? 3u : 0u) : ((m0 ? 1u : 0u) | (m1 ? 2u : 0u));
+                if (kind == K_GATED) bits = 0;
                 bits <<= 2 * q;
                 bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
                 bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
@@ -514,6 +525,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
         // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
         count = zeroes ? (pa.match_zero ? FIXED_LEN : 0) : cnt;
+        if (kind == K_GATED) count = 0;
     }
     if (live && q == 0)
         sec_res[slot] = kind == K_SKIP ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
@@ -564,18 +576,24 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         const uint64_t left = s < sB ? sB - s : 0;
         const uint32_t avail = (uint32_t)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
         const uint64_t off = desc_off(d);
-        const uint64_t off0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(off >> 32)) << 32) |
-                              __builtin_amdgcn_readfirstlane((uint32_t)off);
+        // gated sections need no bytes: the span runs from the first to the last section that does
+        const bool wants = sec < avail && desc_kind(d) != K_GATED;
+        const unsigned long long mw = __ballot(wants);
+        const int f = mw ? (int)__builtin_ctzll(mw) : 0;
+        const uint64_t off0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), f) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)off, f);
         c.gb = off0 & ~15ull;
         uint32_t len = desc_len(d);
         c.len = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
         const uint64_t endl = off + c.len - c.gb; // wraps to a huge value if off < gb
-        const bool fits = sec >= avail || endl <= (uint64_t)REGION_SPAN;
+        const bool fits = !wants || endl <= (uint64_t)REGION_SPAN;
         const unsigned long long m = __ballot(fits);
         uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> 2;
         c.n = n < avail ? n : avail;
-        // section offsets do not decrease with the slot number, so the span ends with its last section
-        const uint32_t e = c.n ? __builtin_amdgcn_readlane((uint32_t)endl, (int)(4 * (c.n - 1))) : 0u;
+        // section offsets do not decrease with the slot number, so the span ends with the last of the
+        // chunk's sections that wants bytes
+        const unsigned long long mn = c.n >= 16 ? mw : mw & ((1ull << (4 * c.n)) - 1ull);
+        const uint32_t e = mn ? __builtin_amdgcn_readlane((uint32_t)endl, 63 - (int)__builtin_clzll(mn)) : 0u;
         c.nch = (e + 15) >> 4;
         c.rel = (uint32_t)(off - c.gb);
         c.kind = sec < c.n ? desc_kind(d) : K_SKIP;
@@ -617,17 +635,21 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         d_next = load_desc(s_next + nxt.n);
         // ---- walk + decode the current chunk ----------------------------------------------------------------------
         const bool has_octets = cur.kind == K_NP || cur.kind == K_DELTA || cur.kind == K_XOR || cur.kind == K_RAW;
-        if ((MODE == MODE_FILTER || MODE == MODE_FILTER_BITS) && cur.n != 0 && __ballot(has_octets) == 0) {
-            // A chunk of Null / Const sections only (sparse vectors): no octet to walk, every section's
-            // count follows from its kind (src/filter.rs:222-223, :104-106; a Const section is 256 copies
-            // of one value).
-            if (sec < cur.n && (lane & 3) == 0) {
-                uint32_t r = res_pack(0, 0); // K_SKIP
-                if (cur.kind == K_NULL) r = res_pack(pa.match_zero ? FIXED_LEN : 0, 0);
-                else if (cur.kind == K_CONST)
-                    r = res_pack(pred_match<ETYPE, SINGLE>(pa, lds_load_unaligned<W>(lds_base + cur.rel + 1u)) ? FIXED_LEN : 0, 0);
-                else if (cur.kind == K_ILLEGAL) r = res_pack(0, CVEC_INVALID_FORMAT);
-                sec_res[s_cur + sec] = r;
+        if (MODE != MODE_DECODE && cur.n != 0 && __ballot(has_octets) == 0) {
+            // A chunk of Null / Const / gated sections only (sparse vectors, or a column behind a
+            // selective one): no octet to walk, every section's count and mask follow from its kind
+            // (src/filter.rs:222-223, :104-106; a Const section is 256 copies of one value).
+            if (sec < cur.n) {
+                bool all = false;
+                if (cur.kind == K_NULL) all = pa.match_zero != 0;
+                else if (cur.kind == K_CONST) all = pred_match<ETYPE, SINGLE>(pa, lds_load_unaligned<W>(lds_base + cur.rel + 1u));
+                if ((lane & 3) == 0)
+                    sec_res[s_cur + sec] = cur.kind == K_ILLEGAL ? res_pack(0, CVEC_INVALID_FORMAT)
+                                                                 : res_pack(all ? FIXED_LEN : 0, 0);
+                if (MODE == MODE_FILTER_MASKS && cur.kind != K_SKIP && cur.kind != K_ILLEGAL) {
+                    const uint32_t m = all ? ~0u : 0u; // each lane of the quad: 8 of the section's 32 mask bytes
+                    *(uint2 *)(masks + (s_cur + sec) * 32 + 8 * (lane & 3)) = make_uint2(m, m);
+                }
             }
         } else if (cur.n != 0 && sa._pad != 1) {
             const bool odd = process_chunk<ETYPE, MODE, SINGLE, false>(data, lds_base, cur.kind, cur.rel, cur.len,
@@ -816,13 +838,13 @@ template <int ETYPE>
 static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                           uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
-                          hipStream_t stream) {
+                          const uint8_t *d_gate, hipStream_t stream) {
     const uint64_t n = b.n_vectors, ns = b.n_sections;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
     timer_mark(rec, 0, stream);
     k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
-                                                                                 n, (b.n_bytes + 15) & ~15ull, desc, vstatus,
-                                                                                 d_result);
+                                                                                 n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
+                                                                                 vstatus, d_result);
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, stream);
@@ -836,19 +858,19 @@ static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &p
 
 hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
                        uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
-                       int32_t *d_status, uint8_t *d_masks, void *d_out, hipStream_t stream) {
+                       int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, hipStream_t stream) {
     switch (b.etype) {
     case CVEC_U32:
         launch_read_t<CVEC_U32>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
-                                d_out, stream);
+                                d_out, d_gate, stream);
         break;
     case CVEC_U64:
         launch_read_t<CVEC_U64>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
-                                d_out, stream);
+                                d_out, d_gate, stream);
         break;
     case CVEC_F32:
         launch_read_t<CVEC_F32>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
-                                d_out, stream);
+                                d_out, d_gate, stream);
         break;
     default: return hipErrorInvalidValue;
     }

@@ -13,9 +13,10 @@ constexpr int HEADER_BYTES = 16; // vector header (reference src/vector.rs:110)
 constexpr int DELTA_HDR = 12;    // Delta section header (reference src/section.rs:607)
 
 // Section kinds as stored in a section descriptor: the reference's type bytes
-// (src/section.rs:32-38) plus two internal markers.
+// (src/section.rs:32-38) plus internal markers.
 constexpr uint32_t K_NULL = 0, K_NP = 1, K_DELTA = 3, K_CONST = 5, K_XOR = 6;
 constexpr uint32_t K_RAW = 2;        // internal: up to 32 bare octets of a legacy NibblePack stream, no section header
+constexpr uint32_t K_GATED = 4;      // internal: well-formed section that a gate switched off: no decode, empty mask
 constexpr uint32_t K_ILLEGAL = 0x7e; // well-formed section of a kind the element type cannot hold
 constexpr uint32_t K_SKIP = 0x7f;    // slot after a parse error / beyond the sections found
 

@@ -134,6 +134,15 @@ cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred
                                   uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
                                   void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The same, behind a gate: d_gate (nullable, 16-byte aligned) holds n_sections * 32 bytes, the masks
+ * an earlier filter pass wrote for a batch with the same sec_base (e.g. the previous column of a
+ * MultiVectorFilter).  A section whose gate mask is empty is parsed but not decoded, like the
+ * short-circuit of src/filter.rs:277-282 (advance(), :204-209): it yields an empty mask, count 0 and
+ * no decode error.  d_masks must be 8-byte aligned. */
+cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const uint8_t *d_gate,
+                                        uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
+                                        uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of the batch.
  * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out (16-byte aligned) holds
  * 256 * n_sections elements of the batch's type (layout: see cvec_dbatch_view). */

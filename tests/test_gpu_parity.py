@@ -386,6 +386,65 @@ def test_multi_vector_filter_and_positions_vs_oracle(cv, oracle):
         assert np.array_equal(pos[int(off[v]):int(off[v + 1])].astype(np.uint64), want), v
 
 
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_gated_columns_equal_ungated_and_oracle(cv, oracle, tname):
+    """Columns behind a selective one are gated by its masks (sections it ruled out are parsed, not
+    decoded, src/filter.rs:277-282): totals, per-row counts and ANDed masks equal the ungated path and
+    the oracle; a decode error inside a gated-off section goes unnoticed, as in the reference."""
+    rng = np.random.default_rng(300 + ET[tname])
+    n, length = 400, 1536                      # same layout in every column: 6 sections per vector
+    def column(p_hit):
+        x = rng.integers(1, 6, size=(n, length)).astype(NPD[tname])
+        hit = rng.random((n, length // 256)) < p_hit             # sections that contain the value 9 at all
+        x[np.repeat(hit, 256, axis=1) & (rng.random((n, length)) < 0.3)] = 9
+        return x
+    cols_np = [column(0.08), column(0.5), column(0.5)]
+    eo = np.arange(n + 1, dtype=np.uint64) * length
+    devs = [cv.encode_batch(tname, c.reshape(-1), eo).to_device() for c in cols_np]
+    preds = [9, 9, 3]
+    total, per_row, masks, rows = cv.multi_filter(devs, preds, per_row=True, return_masks=True)
+    plain = [d.filter_masks(p) for d, p in zip(devs, preds)]
+    t2, per2, masks2, rows2 = cv.multi_filter_count(plain, per_row=True, return_masks=True)
+    assert total == t2 and np.array_equal(per_row, per2) and np.array_equal(masks, masks2) and np.array_equal(rows, rows2)
+    want = (cols_np[0] == 9) & (cols_np[1] == 9) & (cols_np[2] == 3)
+    assert total == int(want.sum()) and np.array_equal(per_row, want.sum(axis=1).astype(np.uint64))
+    host = [d.download() for d in devs]
+    for v in (0, 7, n - 1):
+        cnt = oracle.multi_filter_count(ET[tname], [h.vector(v) for h in host], preds)
+        assert cnt == per_row[v]
+    # the gate really switches sections off: the gated second column matches less often than the plain one
+    g1 = devs[1].filter_masks(preds[1], gate=plain[0])
+    assert int(g1.result[0].item()) < int(plain[1].result[0].item())
+    assert torch_equal_where_gate_open(g1.masks, plain[1].masks, plain[0].masks)
+    # damage an octet of a section of column 1 that column 0 rules out: unnoticed behind the gate
+    m0 = plain[0].masks.cpu().numpy().reshape(-1, 32)
+    closed = np.flatnonzero(~m0.any(axis=1))
+    s = int(closed[len(closed) // 2])
+    v, k = divmod(s, length // 256)
+    h1 = host[1]
+    vec = bytearray(h1.vector(v))
+    pos = 16
+    for _ in range(k):
+        pos += oracle.section_parse(ET[tname], bytes(vec[pos:]))[1]
+    kind, nb = oracle.section_parse(ET[tname], bytes(vec[pos:]))
+    hdr = 12 if kind == 3 else 3
+    vec[pos + hdr + 1] = 0xf0                                      # 16 nibbles per value: an invalid octet
+    vecs = [h1.vector(i) for i in range(n)]
+    vecs[v] = bytes(vec)
+    bad = cv.EncodedBatch.from_vectors(tname, vecs).to_device()
+    _, _, st = bad.filter_count(preds[1], per_vector=True, return_status=True)
+    if tname != "u64":
+        assert st[v] != 0                                          # the plain pass does see it
+    tg, perg = cv.multi_filter([devs[0], bad, devs[2]], preds, per_row=True)
+    assert tg == total and np.array_equal(perg, per_row)
+
+
+def torch_equal_where_gate_open(got, plain, gate):
+    g, p, m = (x.cpu().numpy().reshape(-1, 32) for x in (got, plain, gate))
+    open_ = m.any(axis=1)
+    return np.array_equal(g[open_], p[open_]) and not g[~open_].any()
+
+
 def test_legacy_stream_codecs_vs_oracle(cv, oracle):
     """pack_u64_delta / DeltaSink and pack_f64_xor / DoubleXorSink (src/nibblepacking.rs:15-45, :239-325,
     :392-400) over batches of ragged streams: packed bytes and unpacked values equal the oracle's."""
