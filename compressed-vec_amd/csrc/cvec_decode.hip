@@ -313,7 +313,7 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
 template <int ETYPE, int MODE, bool SINGLE, bool CAREFUL>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
-                                              const SinkArgs &sa, uint32_t *__restrict__ sec_res,
+                                              const SinkArgs &sa, uint32_t &sec_result,
                                               uint8_t *__restrict__ masks, void *__restrict__ out_) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
@@ -558,8 +558,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         count = zeroes ? (pa.match_zero ? FIXED_LEN : 0) : cnt;
         if (kind == K_GATED) count = 0;
     }
-    if (live && q == 0)
-        sec_res[slot] = kind == K_SKIP ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
+    sec_result = kind == K_SKIP ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
     return isoct && (racc & 0x88u) != 0;
 }
 
@@ -650,6 +649,15 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     ChunkPlan cur;
     cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP;
     uint64_t d_next = load_desc(sA);
+    // A chunk's per-section results are stored one loop pass later, behind the wait for the prefetched
+    // bytes: loads and stores share one in-order counter only among their own kind, so a wait for loads
+    // while a store is in flight has to drain the store too (a write round trip per chunk otherwise).
+    uint32_t res_word = 0;
+    uint64_t res_slot = 0;
+    bool res_pending = false;
+    // A use of the first descriptor ahead of the loop: entering the loop with that load in flight would
+    // put a full wait in front of the plan in every pass, right behind the deferred store.
+    asm volatile("" ::"v"(d_next));
     for (;;) {
         // ---- registers -> staging region ---------------------------------------------------------------------
         {
@@ -657,6 +665,9 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
 #pragma unroll
             for (int i = 0; i < REGION_PIECES; i++) dst[64 * i + lane] = R[i];
         }
+        __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
+        if (res_pending) sec_res[res_slot] = res_word;
+        res_pending = false;
         // ---- plan the next chunk and start its loads ------------------------------------------------------------
         // (unconditional, so that the staging registers never become conditionally assigned: past the
         // wave's range the plan is empty and the loads fetch nothing)
@@ -674,9 +685,9 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                 bool all = false;
                 if (cur.kind == K_NULL) all = pa.match_zero != 0;
                 else if (cur.kind == K_CONST) all = pred_match<ETYPE, SINGLE>(pa, lds_load_unaligned<W>(lds_base + cur.rel + 1u));
-                if ((lane & 3) == 0)
-                    sec_res[s_cur + sec] = cur.kind == K_ILLEGAL ? res_pack(0, CVEC_INVALID_FORMAT)
-                                                                 : res_pack(all ? FIXED_LEN : 0, 0);
+                res_word = cur.kind == K_ILLEGAL ? res_pack(0, CVEC_INVALID_FORMAT) : res_pack(all ? FIXED_LEN : 0, 0);
+                res_slot = s_cur + sec;
+                res_pending = (lane & 3) == 0;
                 if (MODE == MODE_FILTER_MASKS && cur.kind != K_SKIP && cur.kind != K_ILLEGAL) {
                     const uint32_t m = all ? ~0u : 0u; // each lane of the quad: 8 of the section's 32 mask bytes
                     *(uint2 *)(masks + (s_cur + sec) * 32 + 8 * (lane & 3)) = make_uint2(m, m);
@@ -684,16 +695,19 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
             }
         } else if (cur.n != 0 && sa._pad != 1) {
             const bool odd = process_chunk<ETYPE, MODE, SINGLE, false>(data, lds_base, cur.kind, cur.rel, cur.len,
-                                                                       sec < cur.n, s_cur + sec, lane, pa, sa, sec_res,
+                                                                       sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
                                                                        masks, out_);
             if (__ballot(odd) != 0)
                 process_chunk<ETYPE, MODE, SINGLE, true>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
-                                                         s_cur + sec, lane, pa, sa, sec_res, masks, out_);
+                                                         s_cur + sec, lane, pa, sa, res_word, masks, out_);
+            res_slot = s_cur + sec;
+            res_pending = sec < cur.n && (lane & 3) == 0;
         }
         if (nxt.n == 0) break;
         s_cur = s_next;
         cur = nxt;
     }
+    if (res_pending) sec_res[res_slot] = res_word;
 }
 
 // ------------------------------------------------------------------------------------------------
