@@ -166,44 +166,66 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     }
     uint64_t k = 0, pos = HEADER_BYTES;
     if (st == CVEC_OK) {
-        while (pos < L) { // sections are walked to the end of the slice (src/vector.rs:443)
-            const uint64_t rem = L - pos;
-            const uint32_t hw = load4(start + pos);
-            const uint32_t b0 = hw & 0xffu;
-            uint64_t nb = 0;
-            int e = CVEC_OK;
-            if (b0 == K_NULL) {
-                nb = 1;
-            } else if (b0 == K_CONST) {
-                if (rem < 1 + (uint64_t)W) e = CVEC_INPUT_TOO_SHORT;
-                nb = 1 + W;
-            } else if (b0 == K_NP || b0 == K_DELTA || b0 == K_XOR) {
-                if (rem <= 1) e = CVEC_BAD_OFFSET;
-                else if (rem < 3) e = CVEC_NOT_ENOUGH_SPACE;
-                else {
-                    uint32_t n16 = (hw >> 8) & 0xffffu;
-                    nb = b0 == K_NP ? (uint64_t)n16 + 3 : (b0 == K_DELTA ? (uint64_t)n16 + DELTA_HDR : n16);
-                    if (nb > rem) e = CVEC_SCROLL_ERR;
-                    else if (nb < 3) e = CVEC_INVALID_FORMAT;
+        // Sections are walked to the end of the slice (src/vector.rs:443), eight at a time: their
+        // descriptors collect in registers and are stored after the eighth.  A store between two header
+        // loads would make every load wait for that store's round trip as well (loads and stores in
+        // flight cannot be told apart by the wait counter).
+        bool walking = true;
+        while (walking && pos < L) {
+            uint64_t found[8];
+            int nfound = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                found[j] = 0;
+                if (walking && pos < L) {
+                    const uint64_t rem = L - pos;
+                    const uint32_t hw = load4(start + pos);
+                    const uint32_t b0 = hw & 0xffu;
+                    uint64_t nb = 0;
+                    int e = CVEC_OK;
+                    if (b0 == K_NULL) {
+                        nb = 1;
+                    } else if (b0 == K_CONST) {
+                        if (rem < 1 + (uint64_t)W) e = CVEC_INPUT_TOO_SHORT;
+                        nb = 1 + W;
+                    } else if (b0 == K_NP || b0 == K_DELTA || b0 == K_XOR) {
+                        if (rem <= 1) e = CVEC_BAD_OFFSET;
+                        else if (rem < 3) e = CVEC_NOT_ENOUGH_SPACE;
+                        else {
+                            uint32_t n16 = (hw >> 8) & 0xffffu;
+                            nb = b0 == K_NP ? (uint64_t)n16 + 3 : (b0 == K_DELTA ? (uint64_t)n16 + DELTA_HDR : n16);
+                            if (nb > rem) e = CVEC_SCROLL_ERR;
+                            else if (nb < 3) e = CVEC_INVALID_FORMAT;
+                        }
+                    } else {
+                        e = CVEC_INVALID_SECTION_TYPE;
+                    }
+                    if (e == CVEC_OK && k >= nslots) e = CVEC_ERR_SECTION_COUNT;
+                    if (e) {
+                        st = e;
+                        walking = false;
+                    } else {
+                        const bool legal = ETYPE == CVEC_F32 ? (b0 == K_NULL || b0 == K_CONST || b0 == K_XOR) : (b0 != K_XOR);
+                        // A section whose gate mask (the 256-bit mask of the same slot of an earlier column)
+                        // is empty is only parsed, like MultiVectorFilter's advance() (src/filter.rs:204-209,
+                        // :279-282).
+                        bool off = false;
+                        if (gate) {
+                            const uint4 *g = (const uint4 *)(gate + 32 * (slot0 + k));
+                            const uint4 a = g[0], b = g[1];
+                            off = ((a.x | a.y | a.z | a.w) | (b.x | b.y | b.z | b.w)) == 0;
+                        }
+                        found[j] = off ? desc_pack(start + pos, 0, K_GATED)
+                                       : desc_pack(start + pos, (uint32_t)nb, legal ? b0 : K_ILLEGAL);
+                        nfound = j + 1;
+                        pos += nb;
+                        k++;
+                    }
                 }
-            } else {
-                e = CVEC_INVALID_SECTION_TYPE;
             }
-            if (e) { st = e; break; }
-            if (k >= nslots) { st = CVEC_ERR_SECTION_COUNT; break; }
-            const bool legal = ETYPE == CVEC_F32 ? (b0 == K_NULL || b0 == K_CONST || b0 == K_XOR) : (b0 != K_XOR);
-            // A section whose gate mask (the 256-bit mask of the same slot of an earlier column) is empty
-            // is only parsed, like MultiVectorFilter's advance() (src/filter.rs:204-209, :279-282).
-            bool off = false;
-            if (gate) {
-                const uint4 *g = (const uint4 *)(gate + 32 * (slot0 + k));
-                const uint4 a = g[0], b = g[1];
-                off = ((a.x | a.y | a.z | a.w) | (b.x | b.y | b.z | b.w)) == 0;
-            }
-            desc[slot0 + k] = off ? desc_pack(start + pos, 0, K_GATED)
-                                  : desc_pack(start + pos, (uint32_t)nb, legal ? b0 : K_ILLEGAL);
-            pos += nb;
-            k++;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j < nfound) desc[slot0 + k - nfound + j] = found[j];
         }
         if (st == CVEC_OK && k != nslots) st = CVEC_ERR_SECTION_COUNT;
     }
