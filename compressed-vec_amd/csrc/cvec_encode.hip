@@ -507,6 +507,11 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
             }
             transform_section<ETYPE>(x, p.kind, p.minv, lane);
             image_octets<U>(x, lane, buf, phase, hdr, 32);
+            // The next section's values are waited for here, ahead of this section's stores: a wait for
+            // loads also drains every store in flight (the counter cannot tell them apart), and at this
+            // point the only stores in flight are the previous section's, a whole section old.
+#pragma unroll
+            for (int i = 0; i < 4; i++) asm volatile("" ::"v"(xn[i]));
             image_copy_out(buf, phase, size, dst, lane);
         }
 #pragma unroll
