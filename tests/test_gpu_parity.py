@@ -623,6 +623,37 @@ def test_host_buffer_entry_points_chunked_vs_oracle(cv, oracle, monkeypatch, chu
     assert e.n_vectors == 0 and e.blob.size == 0 and cv.filter_count_host(e, 1) == 0
 
 
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_vectors_far_beyond_64k_bytes_vs_oracle(cv, oracle, tname):
+    """Vectors of hundreds of sections (several hundred KiB each): section offsets and remaining
+    lengths do not fit 16 bits (the reference's length checks wrap there, src/section.rs:537, :616,
+    :694; this library compares in 64 bits) and one vector spans many waves of the section kernel."""
+    rng = np.random.default_rng(900 + ET[tname])
+    lens = [300_000, 1, 70_001, 256 * 300]
+    parts = []
+    for ln in lens:
+        if tname == "f32":
+            x = (rng.integers(0, 2000, ln) / np.float32(7)).astype(np.float32)
+        else:
+            x = (rng.integers(0, 1 << 20, ln) + (1 << 33 if tname == "u64" else 0)).astype(NPD[tname])
+        x[ln // 3:ln // 3 + 700] = 0                                  # a run of Null sections inside
+        parts.append(x)
+    vals = np.concatenate(parts)
+    eo = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+    assert int(bo[1] - bo[0]) > 65536
+    got = cv.encode_batch(tname, vals, eo)
+    assert np.array_equal(got.byte_off, bo) and np.array_equal(got.blob, blob)
+    dev = got.to_device()
+    dec, out_off = dev.decode()
+    for v, ln in enumerate(lens):
+        assert np.array_equal(_bits(dec[int(out_off[v]):int(out_off[v]) + ln]), _bits(parts[v]))
+    for p in (0, parts[0][5]):
+        total, per = dev.filter_count(p, per_vector=True)
+        wtotal, wper, _, rc = oracle.batch_filter_count(ET[tname], blob, bo, p)
+        assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
