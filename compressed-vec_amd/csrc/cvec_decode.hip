@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
 // k_sections
 // ------------------------------------------------------------------------------------------------
 constexpr int TILE = 16; // sections per chunk: one per quad of lanes
-// Staging region of one wave: 18 KiB = 18 LDS-DMA wave instructions of 1 KiB; holds 16 worst-case
+// Staging region of one wave: 18 KiB = 18 wave-wide 16-byte loads / LDS writes of 1 KiB; holds 16 worst-case
 // u32/f32 sections (1100 B) plus the vector headers between them.  Four waves per workgroup, two
 // workgroups per CU: 144 of the CU's 160 KiB.
 constexpr int REGION_PIECES = 18;
