@@ -397,19 +397,19 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     auto front = [&](Oct &o, uint32_t &mask_n, uint32_t &nw_n) {
         // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2; then the reads of the
         //      next octet's header (after the last octet: a harmless read of the bytes that follow) ------
-        const uint32_t hn = nw >> 4; // n - 1
+        //      in eighths of a byte with the field width n4 = 4n that the extraction needs anyway:
+        //      (n4 * cnt + 20) / 8 = 2 + (n * cnt + 1) / 2, and 8 / 8 for the empty octet
+        uint32_t n4;                        // field width in bits, 4 * ((nw >> 4) + 1), as ONE instruction
+        asm("v_lshl_add_u32 %0, %1, 2, 4" : "=v"(n4) : "v"(nw >> 4));
         const uint32_t pc = __popc(mask);
-        const uint32_t a3 = (uint32_t)__umul24(min(mask, 1u), 3u) + (pc + 2u);
         const uint32_t pa_cur = pa_;
-        pa_ += ((uint32_t)__umul24(hn, pc) + a3) >> 1;
+        pa_ += ((uint32_t)__umul24(n4, pc) + (mask ? 20u : 8u)) >> 3;
         // mask and nw pass through the statement so that everything below is scheduled behind it
         asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1"
                      : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
                      : "v"(pa_)
                      : "memory");
         // ---- address of the lane's two fields, their reads ---------------------------------------------
-        uint32_t n4;                        // field width in bits, 4 * (hn + 1), as ONE instruction
-        asm("v_lshl_add_u32 %0, %1, 2, 4" : "=v"(n4) : "v"(nw >> 4));
         const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
         const uint32_t A = pa_cur + 2u + (b0 >> 3);
         o.s = (A << 3) | (b0 & 4u); // funnel shift; only bits 4:0 are used
