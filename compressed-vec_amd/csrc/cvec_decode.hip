@@ -410,10 +410,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
                      : "v"(pa_)
                      : "memory");
         // ---- address of the lane's two fields, their reads ---------------------------------------------
-        const uint32_t b0 = (uint32_t)__umul24(__popc(mask & lowmask), n4); // bit offset of the first field
-        const uint32_t A = pa_cur + 2u + (b0 >> 3);
-        o.s = (A << 3) | (b0 & 4u); // funnel shift; only bits 4:0 are used
-        const uint32_t qa = A & ~3u;
+        // bit address of the first field: behind the two header bytes, idx fields of n4 bits further on
+        const uint32_t B = (uint32_t)__umul24(__popc(mask & lowmask), n4) + ((pa_cur << 3) + 16u);
+        o.s = B; // funnel shift; only bits 4:0 are used
+        const uint32_t qa = (B >> 3) & ~3u;
         if constexpr (W == 4) {
             asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
                          : "=&v"(o.d01), "=&v"(o.d2)
