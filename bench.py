@@ -274,6 +274,25 @@ def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
     del out
     t = _time_gpu(torch, lambda: cv.encode_device("f32", values, elem_off), 5)
     ex["encode_all_GBs"] = round(raw_bytes / t / 1e9, 2)
+    # two independent filter steps in flight on two streams (the short index / finalize kernels and the
+    # launch gaps of one step hide behind the section kernel of the other)
+    pred = cv.make_pred(cv.F32, PRED)
+    views = [batch, cv.DeviceBatch(batch.etype, batch.d_bytes, batch.d_byte_off, batch.d_sec_base, batch.n_vectors,
+                                   batch.n_sections, batch.n_bytes)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    results = [v.result_buffer() for v in views]
+    torch.cuda.synchronize()
+
+    def two_in_flight(iters):
+        for i in range(iters):
+            with torch.cuda.stream(streams[i & 1]):
+                views[i & 1].filter_count_async(pred, result=results[i & 1])
+        torch.cuda.synchronize()
+
+    two_in_flight(6)
+    t0 = time.perf_counter()
+    two_in_flight(40)
+    ex["filter_two_steps_in_flight_GBs"] = round(raw_bytes * 40 / (time.perf_counter() - t0) / 1e9, 2)
     # host-inclusive: inputs start and results end in page-locked host memory; the library pipelines
     # chunks of vectors through three device slots (copy-in, kernels and copy-out overlap)
     from compressed_vec_amd import hostpath
