@@ -270,24 +270,21 @@ __device__ inline typename Elem<W>::U lds_load_unaligned(uint32_t addr) {
                 ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
 }
 
-template <int ETYPE, bool SINGLE>
+// NPRED = number of predicate values compared, a compile-time bucket (1, 2, 4, 8, 16): the values sit
+// in scalar registers and the compares are straight-line code.  (A run-time loop over pa.count reads
+// the values from the kernel arguments inside the octet loop, and the wait for those scalar loads is
+// the same counter the loop's LDS pipeline runs on: 3x slower for four values.)  The launcher pads
+// the list to the bucket with copies of its first value.
+template <int ETYPE, int NPRED>
 __device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CVEC_U64 ? 8 : 4)>::U x) {
-    if constexpr (SINGLE) {
-        if constexpr (ETYPE == CVEC_F32) return __uint_as_float((uint32_t)x) == __uint_as_float((uint32_t)pa.v[0]);
-        else if constexpr (ETYPE == CVEC_U32) return (uint32_t)x == (uint32_t)pa.v[0];
-        else return x == pa.v[0];
-    } else {
-        bool m = false;
-        if constexpr (ETYPE == CVEC_F32) {
-            const float f = __uint_as_float((uint32_t)x);
-            for (uint32_t p = 0; p < pa.count; p++) m |= (f == __uint_as_float((uint32_t)pa.v[p])); // IEEE ==
-        } else if constexpr (ETYPE == CVEC_U32) {
-            for (uint32_t p = 0; p < pa.count; p++) m |= ((uint32_t)x == (uint32_t)pa.v[p]);
-        } else {
-            for (uint32_t p = 0; p < pa.count; p++) m |= (x == pa.v[p]);
-        }
-        return m;
+    bool m = false;
+#pragma unroll
+    for (int p = 0; p < NPRED; p++) {
+        if constexpr (ETYPE == CVEC_F32) m |= __uint_as_float((uint32_t)x) == __uint_as_float((uint32_t)pa.v[p]); // IEEE ==
+        else if constexpr (ETYPE == CVEC_U32) m |= (uint32_t)x == (uint32_t)pa.v[p];
+        else m |= x == pa.v[p];
     }
+    return m;
 }
 
 // Exact status of a section whose octet walk ran past its end or met an over-wide octet: the first
@@ -332,7 +329,7 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
 // more than 8 nibbles or 8 or more trailing zero nibbles (never produced by an encoder: the value
 // would not fit 32 bits) and only records whether one did; the caller then repeats the chunk with
 // CAREFUL = true, which handles both exactly.  Returns that record.
-template <int ETYPE, int MODE, bool SINGLE, bool CAREFUL>
+template <int ETYPE, int MODE, int NPRED, bool CAREFUL>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t &sec_result,
@@ -494,7 +491,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         }
         // ---- epilogue ----------------------------------------------------------------------------------------
         if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
-            const bool m0 = pred_match<ETYPE, SINGLE>(pa, x0), m1 = pred_match<ETYPE, SINGLE>(pa, x1);
+            const bool m0 = pred_match<ETYPE, NPRED>(pa, x0), m1 = pred_match<ETYPE, NPRED>(pa, x1);
             cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
             if constexpr (MODE == MODE_FILTER_MASKS) {
                 // byte k of the section's mask: bits 2q, 2q+1 from each lane of the quad
@@ -602,7 +599,7 @@ struct ChunkPlan {
 // (process_chunk) while the loads fly.  Registers, not a second LDS region, double-buffer the
 // stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
 // No barriers and no cross-wave traffic.
-template <int ETYPE, int MODE, bool SINGLE>
+template <int ETYPE, int MODE, int NPRED>
 __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
@@ -706,7 +703,7 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
             if (sec < cur.n) {
                 bool all = false;
                 if (cur.kind == K_NULL) all = pa.match_zero != 0;
-                else if (cur.kind == K_CONST) all = pred_match<ETYPE, SINGLE>(pa, lds_load_unaligned<W>(lds_base + cur.rel + 1u));
+                else if (cur.kind == K_CONST) all = pred_match<ETYPE, NPRED>(pa, lds_load_unaligned<W>(lds_base + cur.rel + 1u));
                 res_word = cur.kind == K_ILLEGAL ? res_pack(0, CVEC_INVALID_FORMAT) : res_pack(all ? FIXED_LEN : 0, 0);
                 res_slot = s_cur + sec;
                 res_pending = (lane & 3) == 0;
@@ -716,11 +713,11 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                 }
             }
         } else if (cur.n != 0 && sa._pad != 1) {
-            const bool odd = process_chunk<ETYPE, MODE, SINGLE, false>(data, lds_base, cur.kind, cur.rel, cur.len,
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, false>(data, lds_base, cur.kind, cur.rel, cur.len,
                                                                        sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
                                                                        masks, out_);
             if (__ballot(odd) != 0)
-                process_chunk<ETYPE, MODE, SINGLE, true>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
+                process_chunk<ETYPE, MODE, NPRED, true>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
                                                          s_cur + sec, lane, pa, sa, res_word, masks, out_);
             res_slot = s_cur + sec;
             res_pending = sec < cur.n && (lane & 3) == 0;
@@ -869,22 +866,35 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (per < 2 * TILE) per = 2 * TILE;
         const uint64_t nwaves = (ns + per - 1) / per;
         const uint32_t nwg = (uint32_t)((nwaves + SEC_WAVES - 1) / SEC_WAVES);
-        const bool single = pa.count == 1;
         static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
         SinkArgs sa2 = sa;
         sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage the bytes but skip the octet loop, 5 = loop without HBM traffic
-#define CVEC_LAUNCH_SEC(M, S)                                                                                       \
-    k_sections<ETYPE, M, S><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pa, sa2, sec_res, d_masks, d_out)
-        if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, true);
-        else if (d_masks) { if (single) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, true); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, false); }
-        else if (single) {
+        // the predicate list padded to its bucket with copies of the first value
+        PredArgs pb = pa;
+        uint32_t bucket = 1;
+        while (bucket < pb.count) bucket *= 2;
+        for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
+#define CVEC_LAUNCH_SEC(M, N)                                                                                       \
+    k_sections<ETYPE, M, N><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out)
+#define CVEC_LAUNCH_BUCKET(M)                                                                                       \
+    switch (bucket) {                                                                                               \
+    case 1: CVEC_LAUNCH_SEC(M, 1); break;                                                                           \
+    case 2: CVEC_LAUNCH_SEC(M, 2); break;                                                                           \
+    case 4: CVEC_LAUNCH_SEC(M, 4); break;                                                                           \
+    case 8: CVEC_LAUNCH_SEC(M, 8); break;                                                                           \
+    default: CVEC_LAUNCH_SEC(M, 16); break;                                                                         \
+    }
+        if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, 1);
+        else if (d_masks) { CVEC_LAUNCH_BUCKET(MODE_FILTER_MASKS); }
+        else if (bucket == 1) {
             // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN
             const uint32_t fb = (uint32_t)pa.v[0];
             const bool bits_ok = ETYPE != CVEC_F32 || ((fb & 0x7fffffffu) != 0 && (fb & 0x7fffffffu) <= 0x7f800000u);
-            if (bits_ok) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, true); else CVEC_LAUNCH_SEC(MODE_FILTER, true);
+            if (bits_ok) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, 1); else CVEC_LAUNCH_SEC(MODE_FILTER, 1);
         } else {
-            CVEC_LAUNCH_SEC(MODE_FILTER, false);
+            CVEC_LAUNCH_BUCKET(MODE_FILTER);
         }
+#undef CVEC_LAUNCH_BUCKET
 #undef CVEC_LAUNCH_SEC
     }
 }
