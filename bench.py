@@ -32,14 +32,17 @@ PRED = 3.0                     # benches/bench.rs:239
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--vectors-per-gpu", type=int, default=VECS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the encode / decode / PCIe side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "1")),
                     help="independent steps in flight: step i runs on stream i %% streams with its own workspace")
+    ap.add_argument("--prewarm", type=int, default=300,
+                    help="untimed filter passes during set-up, before the warmup steps: the GPU needs a few "
+                         "hundred launches to reach its steady clock (0.207 -> 0.195 ms per section kernel)")
     ap.add_argument("--dist-single", action="store_true",
                     help="take the multi-rank code path (process group, all-reduce) with a single rank; for testing")
     return ap.parse_args()
@@ -165,6 +168,9 @@ def main():
                 pending[j].wait()
                 pending[j] = None
 
+    for _ in range(args.prewarm):          # set-up: clocks to steady state (no collective, not a step)
+        batch.filter_count_async(pred, result=results[0])
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
@@ -219,7 +225,7 @@ def main():
                                "filter == %.1f + count_hits%s" % (nvec, VEC_LEN, PRED,
                                                                   ", RCCL all-reduce of the count" if world > 1 else ""),
                    "vectors_per_gpu": nvec, "vector_len": VEC_LEN, "parallelism": "shard%d" % world,
-                   "steps_in_flight": nstreams,
+                   "steps_in_flight": nstreams, "prewarm_passes": args.prewarm,
                    "compressed_bytes_per_gpu": batch.n_bytes,
                    "compressed_bytes_per_element": round(batch.n_bytes / n_elems, 4)},
     }
