@@ -332,8 +332,8 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
 template <int ETYPE, int MODE, int NPRED, bool CAREFUL>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
-                                              const SinkArgs &sa, uint32_t &sec_result,
-                                              uint8_t *__restrict__ masks, void *__restrict__ out_) {
+                                              const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
+                                              uint32_t &mask_hi, void *__restrict__ out_) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
     const uint32_t q = lane & 3;
@@ -356,6 +356,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         else tgt = (U)pa.v[0] - base;
     }
     uint32_t mism = 0;
+    mask_lo = 0; mask_hi = 0;
     const uint32_t lowmask = (1u << (2 * q)) - 1u;
     uint32_t cnt = 0, hmax = 0, racc = 0;
     const uint32_t q2 = 2 * q;
@@ -500,7 +501,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
                 bits <<= 2 * q;
                 bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
                 bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
-                if (live && q == 0 && kind != K_SKIP && kind != K_ILLEGAL) masks[slot * 32 + k] = (uint8_t)bits;
+                // lane q of the quad collects mask bytes 4q..4q+3 and 16+4q..16+4q+3 (dwords q and 4+q of
+                // the section's mask); the caller stores them once per chunk
+                const uint32_t mine = q == (uint32_t)((k >> 2) & 3) ? bits : 0u;
+                if (k < 16) mask_lo |= mine << (8 * (k & 3)); else mask_hi |= mine << (8 * (k & 3));
             }
         } else {
             if (addc) {
@@ -671,9 +675,9 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     // A chunk's per-section results are stored one loop pass later, behind the wait for the prefetched
     // bytes: loads and stores share one in-order counter only among their own kind, so a wait for loads
     // while a store is in flight has to drain the store too (a write round trip per chunk otherwise).
-    uint32_t res_word = 0;
+    uint32_t res_word = 0, mk_lo = 0, mk_hi = 0; // mask dwords q and 4 + q of the lane's section
     uint64_t res_slot = 0;
-    bool res_pending = false;
+    bool res_pending = false, mk_pending = false;
     // A use of the first descriptor ahead of the loop: entering the loop with that load in flight would
     // put a full wait in front of the plan in every pass, right behind the deferred store.
     asm volatile("" ::"v"(d_next));
@@ -687,6 +691,13 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
         if (res_pending) sec_res[res_slot] = res_word;
         res_pending = false;
+        if constexpr (MODE == MODE_FILTER_MASKS) {
+            if (mk_pending) {
+                uint32_t *m = (uint32_t *)(masks + res_slot * 32) + (lane & 3);
+                m[0] = mk_lo; m[4] = mk_hi;
+            }
+            mk_pending = false;
+        }
         // ---- plan the next chunk and start its loads ------------------------------------------------------------
         // (unconditional, so that the staging registers never become conditionally assigned: past the
         // wave's range the plan is empty and the loads fetch nothing)
@@ -707,26 +718,31 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                 res_word = cur.kind == K_ILLEGAL ? res_pack(0, CVEC_INVALID_FORMAT) : res_pack(all ? FIXED_LEN : 0, 0);
                 res_slot = s_cur + sec;
                 res_pending = (lane & 3) == 0;
-                if (MODE == MODE_FILTER_MASKS && cur.kind != K_SKIP && cur.kind != K_ILLEGAL) {
-                    const uint32_t m = all ? ~0u : 0u; // each lane of the quad: 8 of the section's 32 mask bytes
-                    *(uint2 *)(masks + (s_cur + sec) * 32 + 8 * (lane & 3)) = make_uint2(m, m);
-                }
+                mk_lo = mk_hi = all ? ~0u : 0u;
+                mk_pending = cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
             }
         } else if (cur.n != 0 && sa._pad != 1) {
             const bool odd = process_chunk<ETYPE, MODE, NPRED, false>(data, lds_base, cur.kind, cur.rel, cur.len,
-                                                                       sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
-                                                                       masks, out_);
+                                                                      sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
+                                                                      mk_lo, mk_hi, out_);
             if (__ballot(odd) != 0)
                 process_chunk<ETYPE, MODE, NPRED, true>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
-                                                         s_cur + sec, lane, pa, sa, res_word, masks, out_);
+                                                        s_cur + sec, lane, pa, sa, res_word, mk_lo, mk_hi, out_);
             res_slot = s_cur + sec;
             res_pending = sec < cur.n && (lane & 3) == 0;
+            mk_pending = sec < cur.n && cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
         }
         if (nxt.n == 0) break;
         s_cur = s_next;
         cur = nxt;
     }
     if (res_pending) sec_res[res_slot] = res_word;
+    if constexpr (MODE == MODE_FILTER_MASKS) {
+        if (mk_pending) {
+            uint32_t *m = (uint32_t *)(masks + res_slot * 32) + (lane & 3);
+            m[0] = mk_lo; m[4] = mk_hi;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
