@@ -8,7 +8,7 @@ benches/bench.rs:238-241 of the reference) over the rank's whole batch, which is
 HBM; for N > 1 every rank owns its own shard of vectors (no data exchange) and every step all-reduces
 its 8-byte match count over RCCL (asynchronously: the collective of a step overlaps the kernels of the
 next ones; all of them are complete before the clock stops).  Workload: 131072 vectors x 2048 f32 per GPU (1 GiB of
-uncompressed values per GPU; at N = 8 this is BASELINE.json's config 5: 1 Mi vectors of 2048).
+uncompressed values per GPU; at N = 8 this is the 1 Mi vectors x 2048 f32 configuration the metric is quoted on).
 Rank 0 prints one JSON line; `value` is whole-job GB/s counted in uncompressed bytes."""
 import argparse
 import ctypes as C
