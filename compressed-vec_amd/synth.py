@@ -58,3 +58,28 @@ def batch_values_torch(kind, n_vectors, length, device="cuda", v_first=0):
         vals = u + 100000
     elem_off = torch.arange(n_vectors + 1, device=device, dtype=torch.int64) * length
     return vals.reshape(-1).contiguous(), elem_off
+
+
+def splitmix_f32_torch(n_vectors, length, device="cuda", v_first=0, mantissa_bits=12):
+    """Aperiodic f32 test data: element i of vector v is a float in [1, 2) whose top `mantissa_bits`
+    mantissa bits come from SplitMix64 seeded with 0xC0FFEE + v (the other mantissa bits are zero), so
+    neighbouring values share sign and exponent and differ in a fixed number of bits.
+    Returns (values tensor, elem_off tensor int64)."""
+    import torch
+
+    def srl(x, k):  # logical shift right of int64
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def wrap(c):  # a 64-bit constant as a wrapping int64
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    seed = torch.arange(n_vectors, device=device, dtype=torch.int64)[:, None] + (0xC0FFEE + v_first)
+    idx = torch.arange(1, length + 1, device=device, dtype=torch.int64)[None, :]
+    z = seed + idx * wrap(0x9E3779B97F4A7C15)
+    z = (z ^ srl(z, 30)) * wrap(0xBF58476D1CE4E5B9)
+    z = (z ^ srl(z, 27)) * wrap(0x94D049BB133111EB)
+    z = z ^ srl(z, 31)
+    frac = (z & ((1 << mantissa_bits) - 1)) << (23 - mantissa_bits)
+    bits = (frac | 0x3F800000).to(torch.int32)
+    elem_off = torch.arange(n_vectors + 1, device=device, dtype=torch.int64) * length
+    return bits.view(torch.float32).reshape(-1).contiguous(), elem_off

@@ -27,9 +27,14 @@ def timed(fn, iters=10):
 def run(name, tname, kind, nvec, length, pred, add_const):
     chunks = []
     for c0 in range(0, nvec, 4096):
-        chunks.append(synth.batch_values_torch("u32_dense" if kind == "u32_sparse" else kind, min(4096, nvec - c0),
-                                               length, v_first=c0)[0])
+        if kind == "f32_splitmix":
+            chunks.append(synth.splitmix_f32_torch(min(4096, nvec - c0), length, v_first=c0)[0])
+        else:
+            chunks.append(synth.batch_values_torch("u32_dense" if kind == "u32_sparse" else kind, min(4096, nvec - c0),
+                                                   length, v_first=c0)[0])
     vals = torch.cat(chunks)
+    if pred is None:
+        pred = float(vals[12345].item())        # a value that occurs
     if kind == "u32_sparse":
         # benches/bench.rs:160-170: two runs of 50 values in a vector of nulls (zeros)
         keep = torch.zeros(length, dtype=torch.bool, device="cuda")
@@ -47,7 +52,7 @@ def run(name, tname, kind, nvec, length, pred, add_const):
     t_fil = timed(lambda: batch.filter_count_async(p, result=res))
     got = int(res[0].item())
     want = int((vals == pred).sum().item())
-    if kind != "f32_xor":                       # padding matches a zero predicate only
+    if kind != "f32_xor":                       # (10000-element f32 vectors: the zero padding never matches these predicates either)
         assert got == want, (got, want)
     print(json.dumps({"config": name, "vectors": nvec, "vector_len": length, "raw_MiB": raw >> 20,
                       "compressed_B_per_elem": round(batch.n_bytes / vals.numel(), 3),
@@ -82,4 +87,6 @@ if __name__ == "__main__":
     run("cfg2 u32 sparse", "u32", "u32_sparse", n, 10000, 15, 7)
     run("cfg3 f32 xor", "f32", "f32_xor", n, 10000, 3.0, 2.5)
     run("cfg4 u64 delta", "u64", "u64_delta", n // 2, 10000, 100003, 5)
+    # aperiodic f32 (SplitMix64, 12 mantissa bits) at the benchmark's vector shape
+    run("cfg5 f32 splitmix", "f32", "f32_splitmix", 131072, 2048, None, 2.5)
     run_streams(n // 2, 10000)
