@@ -68,7 +68,26 @@ def cpu_baseline(dev_batch, n_sample_vectors, seconds, pred):
         if dt >= seconds:
             break
     gbs = passes * elems * 4 / dt / 1e9
+    # the same port on 16 threads (the GPU box's CPU share), vectors split evenly; ctypes releases the GIL
+    from concurrent.futures import ThreadPoolExecutor
+    nthr = 16
+    cuts = [n * t // nthr for t in range(nthr + 1)]
+    parts = [(blob[int(bo[cuts[t]]):int(bo[cuts[t + 1]])], bo[cuts[t]:cuts[t + 1] + 1] - bo[cuts[t]]) for t in range(nthr)]
+
+    def one(part):
+        return oracle.batch_filter_count(oracle.F32, part[0], part[1], pred)[0]
+
+    with ThreadPoolExecutor(nthr) as pool:
+        t1 = time.perf_counter()
+        mt_passes, mt_total = 0, None
+        while time.perf_counter() - t1 < seconds / 4:
+            mt_total = sum(pool.map(one, parts))
+            mt_passes += 1
+        mt_dt = time.perf_counter() - t1
+    assert mt_total == total
+    mt_gbs = mt_passes * elems * 4 / mt_dt / 1e9
     return {"value": round(gbs, 4), "unit": "GB/s (uncompressed bytes)", "cores": 1, "kind": "port",
+            "value_16_threads": round(mt_gbs, 3),
             "sample": "first %d of the same %d-element f32 XOR vectors (%d MiB uncompressed), %d passes in %.1f s, "
                       "filter == %.1f + count, oracle/cvec_oracle.c single thread" %
                       (n, VEC_LEN, elems * 4 >> 20, passes, dt, pred)}, total
