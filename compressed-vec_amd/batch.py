@@ -147,6 +147,35 @@ class DeviceBatch:
                                               _stream_ptr()))
         return cls(etype, d_bytes, d_byte_off, d_sec_base, n, nsec.value, n_bytes)
 
+    @classmethod
+    def concat(cls, batches):
+        """One resident batch out of several (same element type, same device): the vectors of the inputs
+        in order.  Vectors are independent, so the blob of the result is the inputs' blobs back to back;
+        only the offsets are rebased (device-side copies, no host round trip)."""
+        batches = list(batches)
+        first = batches[0]
+        if any(b.etype != first.etype or b.device != first.device for b in batches):
+            raise N.CodingError(N.ERR_BAD_ARGUMENT, "batches differ in element type or device")
+        n_bytes = sum(b.n_bytes for b in batches)
+        d_bytes = torch.zeros(((n_bytes + 16 + 255) // 256) * 256, dtype=torch.uint8, device=first.device)
+        offs, secs = [], []
+        at_bytes = at_secs = 0
+        for b in batches:
+            d_bytes[at_bytes:at_bytes + b.n_bytes].copy_(b.d_bytes[:b.n_bytes])
+            offs.append(b.d_byte_off[:-1] + at_bytes)
+            secs.append(b.d_sec_base[:-1] + at_secs)
+            at_bytes += b.n_bytes
+            at_secs += b.n_sections
+        end = torch.tensor([at_bytes], dtype=torch.int64, device=first.device)
+        send = torch.tensor([at_secs], dtype=torch.int64, device=first.device)
+        return cls(first.etype, d_bytes, torch.cat(offs + [end]), torch.cat(secs + [send]),
+                   sum(b.n_vectors for b in batches), at_secs, at_bytes)
+
+    def append_values(self, d_values, d_elem_off):
+        """The batch extended by freshly encoded vectors (Vector*Appender::encode_all on the device for the
+        new values): returns the new DeviceBatch; this one stays valid."""
+        return DeviceBatch.concat([self, encode_device(self.etype, d_values, d_elem_off)])
+
     def download(self):
         blob = self.d_bytes[:self.n_bytes].cpu().numpy()
         off = self.d_byte_off.cpu().numpy().view(np.uint64)

@@ -654,6 +654,34 @@ def test_vectors_far_beyond_64k_bytes_vs_oracle(cv, oracle, tname):
         assert rc == 0 and total == wtotal and np.array_equal(per, wper)
 
 
+def test_resident_batch_grows_by_appended_vectors(cv, oracle):
+    """A batch in HBM extended twice by newly encoded vectors equals the encode of all vectors at once
+    (bytes, offsets, section bases) and filters / decodes like it."""
+    import torch
+    rng = np.random.default_rng(4242)
+    vals, eo = _random_vectors(rng, "u32", 90, max_len=1400)
+    cuts = [0, 25, 26, 90]
+    dev = None
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = torch.from_numpy(vals[int(eo[a]):int(eo[b])].view(np.int32)).cuda()
+        peo = torch.from_numpy((eo[a:b + 1] - eo[a]).view(np.int64)).cuda()
+        if part.numel() == 0:
+            part = torch.zeros(4, dtype=torch.int32, device="cuda")
+        dev = cv.encode_device("u32", part, peo, int(eo[b] - eo[a])) if dev is None else dev.append_values(part, peo)
+    blob, bo = oracle.batch_encode(ET["u32"], vals, eo)
+    host = dev.download()
+    assert np.array_equal(host.byte_off, bo) and np.array_equal(host.blob, blob)
+    whole = cv.EncodedBatch("u32", blob, bo).to_device()
+    assert torch.equal(dev.d_sec_base, whole.d_sec_base) and dev.n_sections == whole.n_sections
+    nz = vals[vals != 0]
+    total, per = dev.filter_count(nz[2], per_vector=True)
+    wtotal, wper, _, rc = oracle.batch_filter_count(ET["u32"], blob, bo, nz[2])
+    assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+    dec, off = dev.decode()
+    want, _, rc = oracle.batch_decode(ET["u32"], blob, bo, off)
+    assert rc == 0 and np.array_equal(dec, want)
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
