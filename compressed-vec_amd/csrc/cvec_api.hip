@@ -192,7 +192,7 @@ cvec_status read_pipeline(bool decode, int32_t etype, const uint8_t *h_bytes, co
         if (h_byte_off[v + 1] - h_byte_off[v] >= (uint64_t)HEADER_BYTES) {
             uint32_t ne;
             memcpy(&ne, h_bytes + h_byte_off[v] + 8, 4);
-            c = ((uint64_t)ne + FIXED_LEN - 1) / FIXED_LEN;
+            c = header_slots(ne, h_byte_off[v + 1] - h_byte_off[v]);
         }
         sec_base[v + 1] = sec_base[v] + c;
     }

@@ -36,7 +36,7 @@ __global__ void k_header_sections(const uint8_t *__restrict__ bytes, const uint6
     uint64_t c = 0;
     if (len >= HEADER_BYTES) {
         uint32_t ne = *(const u32u *)(bytes + start + 8); // FixedSectStats.num_elements, src/vector.rs:165
-        c = ((uint64_t)ne + FIXED_LEN - 1) / FIXED_LEN;
+        c = header_slots(ne, len);
     }
     nsec[v] = c;
 }

@@ -12,6 +12,17 @@ constexpr int FIXED_LEN = 256;   // elements per section (reference src/section.
 constexpr int HEADER_BYTES = 16; // vector header (reference src/vector.rs:110)
 constexpr int DELTA_HDR = 12;    // Delta section header (reference src/section.rs:607)
 
+// Section slots given to a vector of `len` >= HEADER_BYTES bytes whose header claims `num_elements`
+// (reference src/vector.rs:165): ceil(num_elements / 256), except that a claim beyond what the bytes
+// could hold (a section takes at least one byte) gets one slot more than that bound.  The walk can
+// then never fill the slots, the vector still reports a section-count mismatch, and a damaged header
+// cannot make the library size its buffers by anything but the bytes it was given.
+__host__ __device__ inline uint64_t header_slots(uint32_t num_elements, uint64_t len) {
+    const uint64_t claimed = ((uint64_t)num_elements + FIXED_LEN - 1) / FIXED_LEN;
+    const uint64_t bound = len - HEADER_BYTES;
+    return claimed > bound ? bound + 1 : claimed;
+}
+
 // Section kinds as stored in a section descriptor: the reference's type bytes
 // (src/section.rs:32-38) plus internal markers.
 constexpr uint32_t K_NULL = 0, K_NP = 1, K_DELTA = 3, K_CONST = 5, K_XOR = 6;

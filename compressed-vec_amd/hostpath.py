@@ -52,7 +52,7 @@ def filter_count_host(batch, pred, per_vector=False, return_status=False):
     st = np.zeros(n, dtype=np.int32) if return_status else None
     rc = L.cvec_filter_count_batch(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(p), C.byref(total),
                                    _p(per) if per is not None else None, _p(st) if st is not None else None)
-    if rc != N.OK and not (return_status and rc < 100):
+    if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT):
         N.check(rc)
     out = [total.value]
     if per_vector:
@@ -74,13 +74,17 @@ def decode_host(batch, add_const=None, return_status=False, out=None):
     ne = np.zeros(at.size, dtype=np.int64)
     for k in range(4):
         ne |= batch.blob[at + 8 + k].astype(np.int64) << (8 * k)
-    nsec = int(((ne + FIXED_LEN - 1) // FIXED_LEN).sum())
+    # a claim beyond what the bytes could hold (a section takes at least one byte) is cut to one slot
+    # more than that bound, as the library does
+    bound = (batch.byte_off[1:] - batch.byte_off[:-1]).astype(np.int64)[has_header] - 16
+    claimed = (ne + FIXED_LEN - 1) // FIXED_LEN
+    nsec = int(np.where(claimed > bound, bound + 1, claimed).sum())
     vals = out if out is not None else np.zeros(nsec * FIXED_LEN, dtype=NP_DTYPE[batch.etype])
     out_off = np.zeros(n + 1, dtype=np.uint64)
     st = np.zeros(n, dtype=np.int32) if return_status else None
     chain = make_chain(batch.etype, add_const)
     rc = L.cvec_decode_batch(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(chain), _p(vals), vals.size,
                              _p(out_off), _p(st) if st is not None else None)
-    if rc != N.OK and not (return_status and rc < 100):
+    if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT):
         N.check(rc)
     return (vals, out_off, st) if return_status else (vals, out_off)

@@ -314,6 +314,43 @@ def test_malformed_vectors_report_status_and_partial_counts(cv, oracle):
     assert list(dst) == list(wst)
 
 
+def test_damaged_element_count_is_bounded_by_the_bytes(cv, oracle):
+    """A header whose num_elements (src/vector.rs:165) claims far more sections than the vector's bytes
+    could hold must not size any buffer: the vector gets one slot more than its bytes allow, reports a
+    section-count mismatch, and its neighbours decode and count as usual."""
+    good = oracle.encode_all(oracle.U32, (np.arange(600, dtype=np.uint32) % 5) + 1)
+    bad = bytearray(good)
+    bad[8:12] = (0xffffffff).to_bytes(4, "little")
+    host = cv.EncodedBatch.from_vectors("u32", [good, bytes(bad), good])
+    dev = host.to_device()
+    sb = dev.d_sec_base.cpu().numpy()
+    assert int(sb[1] - sb[0]) == 3 and int(sb[2] - sb[1]) == len(good) - 16 + 1 and int(sb[3] - sb[2]) == 3
+    total, per, st = dev.filter_count(3, per_vector=True, return_status=True)
+    assert list(st) == [0, 100, 0]
+    assert per[0] == per[2] == oracle.filter_count(oracle.U32, good, 3)
+    dec, off, dst = dev.decode(return_status=True)
+    assert list(dst) == [0, 100, 0] and dec.size == 256 * int(sb[3])
+    want = oracle.decode_to_vec(oracle.U32, good)
+    assert np.array_equal(dec[:768], want) and np.array_equal(dec[int(off[2]):int(off[2]) + 768], want)
+    vals, hoff, hst = cv.decode_host(host, return_status=True)
+    assert list(hst) == [0, 100, 0] and np.array_equal(hoff, off) and np.array_equal(vals[:768], want)
+
+
+def test_randomly_damaged_batches_vs_oracle(cv, oracle):
+    """A short run of the soak in tools/fuzz_parity.py: random ragged batches with 0, 1, 3 or 12 damaged
+    bytes; statuses, partial counts, masks and decoded values of every vector against the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for seed in range(5000, 5120):
+        for tname in ("u32", "u64", "f32"):
+            assert fz.one_round(seed, tname, [0, 1, 3, 12][seed % 4]) == [], (seed, tname)
+    assert fz.STATS["bad_status"] > 50
+
+
 def test_overwide_shift_octets_take_the_exact_path(cv, oracle):
     """Hand-made 32-bit sections whose octets carry 8 or more trailing zero nibbles (an encoder never
     writes them: the lanes shift out to 0, src/nibblepack_simd.rs:581) must decode like the oracle;

@@ -1,0 +1,167 @@
+"""Randomised soak of the device path against the CPU oracle: well-formed ragged batches and
+batches with randomly damaged bytes (headers, section headers, octet headers, bit streams).
+
+For every seed and element type the statuses, the per-vector counts of an equality filter and of a
+OneOf filter, the masks of the healthy vectors and the decoded values of the healthy vectors must equal
+the oracle's.  Prints one line per mismatch (seed, type, what differed) and a summary; exits non-zero
+on any mismatch.  Usage: python tools/fuzz_parity.py [--seconds 90] [--seed0 0]
+"""
+import argparse
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+cv = importlib.import_module("compressed-vec_amd")
+import oracle  # noqa: E402
+from test_gpu_parity import _random_vectors, _bits, ET, NPD  # noqa: E402
+
+
+def damage(rng, blob, byte_off, n_hits):
+    """Flip or overwrite n_hits random bytes; biased toward structural bytes near section starts."""
+    blob = bytearray(blob)
+    nv = len(byte_off) - 1
+    for _ in range(n_hits):
+        v = int(rng.integers(0, nv))
+        lo, hi = int(byte_off[v]), int(byte_off[v + 1])
+        if hi <= lo:
+            continue
+        how = rng.integers(0, 4)
+        if how == 0:                                  # somewhere in the 16-byte header
+            p = lo + int(rng.integers(0, min(16, hi - lo)))
+        elif how == 1 and hi - lo > 20:               # the first section's header
+            p = lo + 16 + int(rng.integers(0, min(12, hi - lo - 16)))
+        else:                                         # anywhere
+            p = int(rng.integers(lo, hi))
+        if rng.random() < 0.5:
+            blob[p] ^= 1 << int(rng.integers(0, 8))
+        else:
+            blob[p] = int(rng.integers(0, 256))
+    return bytes(blob)
+
+
+STATS = {"vectors": 0, "bad_status": 0, "count_mismatch": 0, "elements_decoded": 0, "matches": 0}
+
+
+def claimed_slots(blob, byte_off, v):
+    """Section slots the library gives vector v: ceil(num_elements / 256) from its header, cut to one more
+    than its bytes could hold."""
+    lo, hi = int(byte_off[v]), int(byte_off[v + 1])
+    if hi - lo < 16:
+        return 0
+    ne = int.from_bytes(bytes(blob[lo + 8:lo + 12]), "little")
+    c, bound = (ne + 255) // 256, hi - lo - 16
+    return bound + 1 if c > bound else c
+
+
+def count_mismatch(et, blob, byte_off, v):
+    """True when the well-formed sections the oracle walks in vector v are not exactly the header's
+    claim: the library reports SectionCountMismatch (100) there, which the reference has no notion of."""
+    lo, hi = int(byte_off[v]), int(byte_off[v + 1])
+    b = np.ascontiguousarray(blob[lo:hi])
+    if oracle.reader_check(et, b)[0] != 0:
+        return False
+    cnt = C.c_size_t(0)
+    rc = oracle.lib().ocv_reader_sections(et, b.ctypes.data_as(C.c_void_p), b.size, C.byref(cnt), None, 0)
+    slots = claimed_slots(blob, byte_off, v)
+    return cnt.value > slots or (rc == 0 and cnt.value != slots)
+
+
+def one_round(seed, tname, hits):
+    rng = np.random.default_rng(seed)
+    flat, off = _random_vectors(rng, tname, int(rng.integers(1, 40)), max_len=int(rng.integers(10, 3000)))
+    et = ET[tname]
+    blob, byte_off = oracle.batch_encode(et, flat, off)
+    blob = bytes(np.asarray(blob, dtype=np.uint8))
+    if hits:
+        blob = damage(rng, blob, byte_off, hits)
+    blob = np.frombuffer(blob, dtype=np.uint8).copy()
+    nv = len(byte_off) - 1
+    host = cv.EncodedBatch(tname, blob, np.asarray(byte_off, dtype=np.uint64))
+    dev = host.to_device()
+    errs = []
+    pick = flat[rng.integers(0, flat.size)] if flat.size else NPD[tname](0)
+    preds = [pick, NPD[tname](0), [pick, NPD[tname](1), NPD[tname](0)]]
+    sb = dev.d_sec_base.cpu().numpy()
+    if [int(sb[v + 1] - sb[v]) for v in range(nv)] != [claimed_slots(blob, byte_off, v) for v in range(nv)]:
+        errs.append(("section slots",))
+        return errs
+    for p in preds:
+        total, per, st, masks = dev.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+        wtotal, wper, wst, _ = oracle.batch_filter_count(et, blob, byte_off, p)
+        STATS["matches"] += int(total)
+        if int(total) != int(np.asarray(per).sum()):
+            errs.append(("total != sum(per)", p))
+        for v in range(nv):
+            if st[v] == 100:
+                if not count_mismatch(et, blob, byte_off, v):
+                    errs.append(("spurious count mismatch", p, v))
+                continue
+            if st[v] != wst[v] and count_mismatch(et, blob, byte_off, v):
+                continue                        # an earlier decode error inside the claimed slots
+            if st[v] != wst[v]:
+                errs.append(("filter status", p, v, int(st[v]), int(wst[v])))
+            elif per[v] != wper[v]:
+                errs.append(("filter count", p, v, int(per[v]), int(wper[v])))
+            elif st[v] == 0:
+                _, wm = oracle.filter_count(et, blob[int(byte_off[v]):int(byte_off[v + 1])], p, return_masks=True)
+                gm = np.asarray(masks[32 * int(sb[v]):32 * int(sb[v + 1])])
+                if not np.array_equal(gm, wm):
+                    errs.append(("masks", p, v))
+    dec, doff, dst = dev.decode(return_status=True)
+    doff = np.asarray(doff)
+    wdec, wst, _ = oracle.batch_decode(et, blob, byte_off, doff)
+    STATS["vectors"] += nv
+    STATS["bad_status"] += int(np.count_nonzero(np.asarray(dst)))
+    STATS["count_mismatch"] += int(np.count_nonzero(np.asarray(dst) == 100))
+    for v in range(nv):
+        if dst[v] == 100:
+            if not count_mismatch(et, blob, byte_off, v):
+                errs.append(("spurious count mismatch in decode", v))
+            continue
+        if dst[v] != wst[v]:
+            if not count_mismatch(et, blob, byte_off, v):
+                errs.append(("decode status", v, int(dst[v]), int(wst[v])))
+        elif dst[v] == 0:
+            a, b = int(doff[v]), int(doff[v + 1])
+            STATS["elements_decoded"] += b - a
+            if not np.array_equal(_bits(np.asarray(dec[a:b])), _bits(np.asarray(wdec[a:b]))):
+                errs.append(("decode values", v))
+    return errs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=90)
+    ap.add_argument("--seed0", type=int, default=0)
+    args = ap.parse_args()
+    t0 = time.time()
+    seed, bad, rounds = args.seed0, 0, 0
+    last = t0
+    while time.time() - t0 < args.seconds:
+        for tname in ("u32", "u64", "f32"):
+            hits = [0, 1, 3, 12][seed % 4]
+            errs = one_round(seed, tname, hits)
+            rounds += 1
+            for e in errs:
+                bad += 1
+                print("MISMATCH seed", seed, tname, "hits", hits, e, flush=True)
+        seed += 1
+        if time.time() - last > 20:
+            last = time.time()
+            print("progress: seeds", seed - args.seed0, "rounds", rounds, "mismatches", bad, flush=True)
+        if bad > 20:
+            break
+    print("fuzz done: rounds", rounds, "mismatches", bad, STATS, flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
