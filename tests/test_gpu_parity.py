@@ -336,19 +336,44 @@ def test_damaged_element_count_is_bounded_by_the_bytes(cv, oracle):
     assert list(hst) == [0, 100, 0] and np.array_equal(hoff, off) and np.array_equal(vals[:768], want)
 
 
-def test_randomly_damaged_batches_vs_oracle(cv, oracle):
-    """A short run of the soak in tools/fuzz_parity.py: random ragged batches with 0, 1, 3 or 12 damaged
-    bytes; statuses, partial counts, masks and decoded values of every vector against the oracle."""
-    import importlib.util
+def _tool(name):
+    """Imports tools/<name>.py (the soak programs; the tests run a short seeded stretch of each)."""
+    import importlib
     import os
-    spec = importlib.util.spec_from_file_location(
-        "fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
-    fz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fz)
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+    return importlib.import_module(name)
+
+
+def test_randomly_damaged_batches_vs_oracle(cv, oracle):
+    """Random ragged batches with 0, 1, 3 or 12 damaged bytes; statuses, partial counts, masks and
+    decoded values of every vector against the oracle."""
+    fz = _tool("fuzz_parity")
     for seed in range(5000, 5120):
         for tname in ("u32", "u64", "f32"):
             assert fz.one_round(seed, tname, [0, 1, 3, 12][seed % 4]) == [], (seed, tname)
     assert fz.STATS["bad_status"] > 50
+
+
+def test_encoder_on_adversarial_values_vs_oracle(cv, oracle):
+    """Extremes of the integer range, ranges that need every bit, chosen zero nibbles, NaN payloads,
+    signed zeros, infinities, denormals: device-encoded bytes equal the oracle's, and decode back."""
+    fz = _tool("fuzz_encode")
+    for seed in range(7000, 7100):
+        for tname in ("u32", "u64", "f32"):
+            assert fz.one_round(seed, tname)[0] == [], (seed, tname)
+
+
+def test_streams_and_columns_randomised_vs_oracle(cv, oracle):
+    """Stream codecs on adversarial values and on damaged or cut packed bytes, and the multi-column filter
+    over columns whose vectors differ in length, against the oracle."""
+    fz = _tool("fuzz_streams")
+    for seed in range(9000, 9060):
+        for kind in ("u64", "u64_delta", "f64_xor"):
+            assert fz.streams_round(seed, kind) == [], (seed, kind)
+        assert fz.columns_round(seed) == [], seed
 
 
 def test_overwide_shift_octets_take_the_exact_path(cv, oracle):
