@@ -134,6 +134,30 @@ def one_round(seed, tname, hits):
             STATS["elements_decoded"] += b - a
             if not np.array_equal(_bits(np.asarray(dec[a:b])), _bits(np.asarray(wdec[a:b]))):
                 errs.append(("decode values", v))
+    if seed % 3 == 0 and nv:
+        # the host-buffer entry points cut the batch into chunks of whole vectors: any chunk size must give
+        # what the resident batch gave
+        os.environ["CVEC_PIPE_CHUNK_BYTES"] = str(int(rng.integers(600, 60000)))
+        try:
+            ht, hper, hst = cv.filter_count_host(host, preds[0], per_vector=True, return_status=True)
+            total, per, st = dev.filter_count(preds[0], per_vector=True, return_status=True)
+            if ht != total or not np.array_equal(hper, per) or list(hst) != list(st):
+                errs.append(("host filter differs", os.environ["CVEC_PIPE_CHUNK_BYTES"]))
+            hv, hoff, hdst = cv.decode_host(host, return_status=True)
+            if list(hdst) != list(dst) or not np.array_equal(np.asarray(hoff), doff):
+                errs.append(("host decode status/offsets differ", os.environ["CVEC_PIPE_CHUNK_BYTES"]))
+            else:
+                for v in range(nv):
+                    a, b = int(doff[v]), int(doff[v + 1])
+                    if dst[v] == 0 and not np.array_equal(_bits(np.asarray(hv[a:b])), _bits(np.asarray(dec[a:b]))):
+                        errs.append(("host decode values differ", v, os.environ["CVEC_PIPE_CHUNK_BYTES"]))
+                        break
+            if not hits:
+                enc = cv.encode_host(tname, flat, off)
+                if not np.array_equal(np.asarray(enc.blob), blob) or not np.array_equal(np.asarray(enc.byte_off), np.asarray(byte_off)):
+                    errs.append(("host encode differs", os.environ["CVEC_PIPE_CHUNK_BYTES"]))
+        finally:
+            del os.environ["CVEC_PIPE_CHUNK_BYTES"]
     return errs
 
 
