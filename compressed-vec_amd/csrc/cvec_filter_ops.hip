@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void k_valid_sections(const uint64_t *__restri
                                                         const uint32_t *__restrict__ sec_res,
                                                         const int32_t *__restrict__ vstatus,
                                                         uint32_t *__restrict__ valid) {
+    (void)vstatus; // a vector that failed its header checks has only K_SKIP slots: nothing more to look up
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const uint64_t a = sec_base[v], b = sec_base[v + 1];
