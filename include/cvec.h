@@ -119,7 +119,11 @@ size_t cvec_workspace_bytes(uint64_t n_vectors, uint64_t n_sections);
 
 /* Computes sec_base[n_vectors+1] from the vector headers (u32 num_elements at +8,
  * src/vector.rs:165) on the device; also returns the section total through h_n_sections (this
- * call synchronises the stream).  Done once per batch, like building byte_off. */
+ * call synchronises the stream).  Done once per batch, like building byte_off.  A vector gets
+ * ceil(num_elements / 256) slots, except that a header claiming more sections than the vector has
+ * bytes behind its header (a section takes at least one byte) gets that many plus one: such a
+ * vector reports CVEC_ERR_SECTION_COUNT, and no buffer is ever sized by a damaged header alone.
+ * The *_batch entry points and the decode output layout (256 elements per slot) use the same rule. */
 cvec_status cvec_sec_base_dev(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_vectors,
                               uint64_t *d_sec_base, uint64_t *h_n_sections, void *stream);
 
