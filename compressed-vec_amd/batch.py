@@ -121,6 +121,8 @@ class DeviceBatch:
         self.view = v
         self._ws = None
         self._result = None
+        self._keep_index = False    # build_index() was called: ungated filters reuse the section index
+        self._index_valid = False   # the workspace holds the ungated index of this batch
 
     @classmethod
     def upload(cls, host, device="cuda", pinned=False):
@@ -202,6 +204,18 @@ class DeviceBatch:
         return raw.view(np.uint32)
 
     # -- operations -------------------------------------------------------------------------------------
+    def build_index(self):
+        """Walks the section headers of every vector once (what each read operation otherwise does as
+        its first kernel) and keeps the result in the batch's workspace: from here on ungated filter
+        passes skip that walk.  The batch is immutable, so the index never goes stale; a gated pass
+        overwrites it and the next ungated pass rebuilds it on the way.  All operations of a batch share
+        its workspace: enqueue them on one stream (or synchronise between streams)."""
+        ws = self.workspace()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().cvec_index_dev(C.byref(self.view), _ptr(ws), ws.numel(), _stream_ptr()))
+        self._keep_index = self._index_valid = True
+        return self
+
     def filter_count_async(self, pred, per_vector=None, status=None, masks=None, result=None, gate=None):
         """Enqueues decode+filter+count on the current stream; returns the device result tensor
         (int64[4]: total, failed vectors, max status, reserved).  `gate`: masks of an earlier pass over
@@ -210,9 +224,15 @@ class DeviceBatch:
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
         with torch.cuda.device(self.device):
-            N.check(N.lib().cvec_filter_count_gated_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
-                                                        _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
-                                                        ws.numel(), _stream_ptr()))
+            if gate is None and self._keep_index and self._index_valid:
+                N.check(N.lib().cvec_filter_count_indexed_dev(C.byref(self.view), C.byref(p), _ptr(res),
+                                                              _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
+                                                              ws.numel(), _stream_ptr()))
+            else:
+                N.check(N.lib().cvec_filter_count_gated_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
+                                                            _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
+                                                            ws.numel(), _stream_ptr()))
+                self._index_valid = gate is None
         return res
 
     def filter_count(self, pred, per_vector=False, return_status=False, return_masks=False):
@@ -258,6 +278,7 @@ class DeviceBatch:
         with torch.cuda.device(self.device):
             N.check(N.lib().cvec_decode_dev(C.byref(self.view), C.byref(chain), _ptr(out), _ptr(res), _ptr(status),
                                             _ptr(ws), ws.numel(), _stream_ptr()))
+        self._index_valid = True
         return res
 
     def decode(self, add_const=None, return_status=False):

@@ -14,8 +14,8 @@ namespace cvec {
 hipError_t launch_sec_base(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n, uint64_t *d_sec_base,
                            uint64_t *d_scratch, hipStream_t stream);
 uint64_t scan_scratch_words(uint64_t n);
-hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
-                       uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
+hipError_t launch_read(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
+                       uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
                        int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, hipStream_t stream);
 hipError_t timing_begin(int max_records);
 hipError_t timing_end(float ms[3], int *n_records);
@@ -414,9 +414,47 @@ cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred
                                        workspace_bytes, stream);
 }
 
+static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, const cvec_pred *pred,
+                                      const uint8_t *d_gate, uint64_t *d_result, uint64_t *d_per_vector,
+                                      int32_t *d_status, uint8_t *d_masks, void *d_workspace, size_t workspace_bytes,
+                                      void *stream);
+
 cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const uint8_t *d_gate,
                                         uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
                                         uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return filter_count_phase(READ_ALL, batch, pred, d_gate, d_result, d_per_vector, d_status, d_masks, d_workspace,
+                              workspace_bytes, stream);
+}
+
+cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, size_t workspace_bytes, void *stream) {
+    cvec_status st = check_view(batch);
+    if (st) return st;
+    if (!d_workspace) return CVEC_ERR_BAD_ARGUMENT;
+    ReadWs w = carve_read_ws(d_workspace, batch->n_vectors, batch->n_sections);
+    if (w.total > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    PredArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    SinkArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    // the index pass clears a result block as its side job; here that block is scratch of the workspace
+    static_assert(CVEC_RESULT_WORDS * 8 <= 256, "the scan scratch is at least 256 bytes");
+    hipError_t e = launch_read(0, READ_INDEX_ONLY, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, w.scan, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_index_dev");
+    return CVEC_OK;
+}
+
+cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
+                                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                          void *d_workspace, size_t workspace_bytes, void *stream) {
+    return filter_count_phase(READ_INDEXED, batch, pred, nullptr, d_result, d_per_vector, d_status, d_masks,
+                              d_workspace, workspace_bytes, stream);
+}
+
+static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, const cvec_pred *pred,
+                                      const uint8_t *d_gate, uint64_t *d_result, uint64_t *d_per_vector,
+                                      int32_t *d_status, uint8_t *d_masks, void *d_workspace, size_t workspace_bytes,
+                                      void *stream) {
     cvec_status st = check_view(batch);
     if (st) return st;
     if (!pred || !d_result || !d_workspace) return CVEC_ERR_BAD_ARGUMENT;
@@ -439,7 +477,7 @@ cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cve
     }
     SinkArgs sa;
     memset(&sa, 0, sizeof(sa));
-    hipError_t e = launch_read(0, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, d_per_vector, d_status,
+    hipError_t e = launch_read(0, phase, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, d_per_vector, d_status,
                                d_masks, nullptr, d_gate, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_filter_count_dev");
     return CVEC_OK;
@@ -462,7 +500,7 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
         sa.add_const = 1;
         sa.base = batch->etype == CVEC_U64 ? chain->add_const_bits : (chain->add_const_bits & 0xffffffffull);
     }
-    hipError_t e = launch_read(1, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status, nullptr,
+    hipError_t e = launch_read(1, READ_ALL, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status, nullptr,
                                d_out, nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_decode_dev");
     return CVEC_OK;

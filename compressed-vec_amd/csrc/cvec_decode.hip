@@ -927,43 +927,50 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     return hipGetLastError();
 }
 
+// phase: READ_ALL = index, sections, finalize; READ_INDEX_ONLY = the index pass alone (descriptors and
+// per-vector header statuses stay in the caller's workspace); READ_INDEXED = sections + finalize over
+// descriptors that an earlier call left there.
 template <int ETYPE>
-static void launch_read_t(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
+static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                           uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
                           const uint8_t *d_gate, hipStream_t stream) {
     const uint64_t n = b.n_vectors, ns = b.n_sections;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
     timer_mark(rec, 0, stream);
-    k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
-                                                                                 n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
-                                                                                 vstatus, d_result);
+    if (phase != READ_INDEXED)
+        k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
+                                                                                     n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
+                                                                                     vstatus, d_result);
+    else
+        (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream); // k_index does this otherwise
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
-    launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, stream);
+    if (phase != READ_INDEX_ONLY)
+        launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, stream);
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
-    if (n > 0)
+    if (n > 0 && phase != READ_INDEX_ONLY)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,
                                                                     d_status, d_result);
     timer_mark(rec, 5, stream);
 }
 
-hipError_t launch_read(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
-                       uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
+hipError_t launch_read(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
+                       uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
                        int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, hipStream_t stream) {
     switch (b.etype) {
     case CVEC_U32:
-        launch_read_t<CVEC_U32>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
-                                d_out, d_gate, stream);
+        launch_read_t<CVEC_U32>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
+                                d_masks, d_out, d_gate, stream);
         break;
     case CVEC_U64:
-        launch_read_t<CVEC_U64>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
-                                d_out, d_gate, stream);
+        launch_read_t<CVEC_U64>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
+                                d_masks, d_out, d_gate, stream);
         break;
     case CVEC_F32:
-        launch_read_t<CVEC_F32>(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks,
-                                d_out, d_gate, stream);
+        launch_read_t<CVEC_F32>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
+                                d_masks, d_out, d_gate, stream);
         break;
     default: return hipErrorInvalidValue;
     }

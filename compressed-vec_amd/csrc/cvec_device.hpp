@@ -23,6 +23,8 @@ __host__ __device__ inline uint64_t header_slots(uint32_t num_elements, uint64_t
     return claimed > bound ? bound + 1 : claimed;
 }
 
+enum { READ_ALL = 0, READ_INDEX_ONLY = 1, READ_INDEXED = 2 }; // phases of a read operation (launch_read)
+
 // Section kinds as stored in a section descriptor: the reference's type bytes
 // (src/section.rs:32-38) plus internal markers.
 constexpr uint32_t K_NULL = 0, K_NP = 1, K_DELTA = 3, K_CONST = 5, K_XOR = 6;

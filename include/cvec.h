@@ -147,6 +147,20 @@ cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cve
                                         uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
                                         uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* A resident section index.  The reference walks the section headers of a vector on every pass
+ * (FixedSectIterator, src/section.rs:866-876) and keeps nothing; the _dev read operations above do
+ * the same walk as their first kernel, for the whole batch, into the workspace (one descriptor per
+ * section slot + one header status per vector).  These two calls split that: cvec_index_dev runs the
+ * walk alone, and cvec_filter_count_indexed_dev is cvec_filter_count_dev without it, over the index
+ * that the workspace still holds.  The caller guarantees that the workspace was last written by
+ * cvec_index_dev, cvec_filter_count_dev, cvec_filter_count_indexed_dev or cvec_decode_dev on this
+ * same batch (an ungated pass: a gated one leaves gated descriptors behind) and that the batch has
+ * not changed since.  Results are identical to cvec_filter_count_dev's. */
+cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, size_t workspace_bytes, void *stream);
+cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
+                                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                          void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of the batch.
  * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out (16-byte aligned) holds
  * 256 * n_sections elements of the batch's type (layout: see cvec_dbatch_view). */

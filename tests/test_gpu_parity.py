@@ -376,6 +376,50 @@ def test_streams_and_columns_randomised_vs_oracle(cv, oracle):
         assert fz.columns_round(seed) == [], seed
 
 
+def test_resident_index_gives_the_same_results(cv, oracle):
+    """build_index() walks the section headers once; later ungated filter passes reuse the descriptors
+    and must return exactly what the full path returns (damaged vectors included); a gated pass in
+    between overwrites the index and the next ungated pass rebuilds it."""
+    rng = np.random.default_rng(41)
+    for tname in ("u32", "u64", "f32"):
+        vals, eo = _random_vectors(rng, tname, 120)
+        blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+        blob = np.array(blob, dtype=np.uint8)
+        for v in (5, 17, 60):                               # damage: a type byte, a length, an octet header
+            lo = int(bo[v])
+            if int(bo[v + 1]) - lo > 40:
+                blob[lo + 16 + (0, 1, 4)[v % 3]] ^= 0x5a
+        host = cv.EncodedBatch(tname, blob, np.asarray(bo, dtype=np.uint64))
+        plain, indexed = host.to_device(), host.to_device().build_index()
+        nz = vals[vals != 0]
+        for p in (0, nz[3], [nz[1], 0, nz[7]]):
+            a = plain.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+            b = indexed.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+            assert indexed._index_valid
+            assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), (tname, p)
+            w = oracle.batch_filter_count(ET[tname], blob, bo, p)
+            assert list(b[2]) == list(w[2]) and np.array_equal(b[1], w[1])
+        # a gated pass in between (gate = all open) leaves gated descriptors behind: the index is rebuilt
+        gate = plain.filter_masks(0)
+        indexed.filter_masks(nz[3], gate=gate)
+        assert not indexed._index_valid
+        a = plain.filter_count(nz[3], per_vector=True, return_status=True)
+        b = indexed.filter_count(nz[3], per_vector=True, return_status=True)
+        assert indexed._index_valid and a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        b = indexed.filter_count(nz[3], per_vector=True, return_status=True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        # decode leaves a valid index behind too
+        d1 = plain.decode(return_status=True)
+        d2 = indexed.decode(return_status=True)
+        assert np.array_equal(_bits(d1[0]), _bits(d2[0])) and np.array_equal(d1[2], d2[2])
+        b = indexed.filter_count(0, per_vector=True, return_status=True)
+        a = plain.filter_count(0, per_vector=True, return_status=True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    # an empty batch
+    e = cv.EncodedBatch.from_vectors("u32", []).to_device().build_index()
+    assert e.filter_count(3) == 0
+
+
 def test_overwide_shift_octets_take_the_exact_path(cv, oracle):
     """Hand-made 32-bit sections whose octets carry 8 or more trailing zero nibbles (an encoder never
     writes them: the lanes shift out to 0, src/nibblepack_simd.rs:581) must decode like the oracle;
