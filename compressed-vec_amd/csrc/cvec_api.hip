@@ -16,7 +16,8 @@ hipError_t launch_sec_base(const uint8_t *d_bytes, const uint64_t *d_byte_off, u
 uint64_t scan_scratch_words(uint64_t n);
 hipError_t launch_read(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                        uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
-                       int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, hipStream_t stream);
+                       int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, uint64_t *tag,
+                       hipStream_t stream);
 hipError_t timing_begin(int max_records);
 hipError_t timing_end(float ms[3], int *n_records);
 // cvec_filter_ops.hip
@@ -363,7 +364,8 @@ struct ReadWs {
     uint64_t *desc;
     uint32_t *sec_res;
     int32_t *vstatus;
-    uint64_t *scan;
+    uint64_t *scan; // 256 bytes or more of scratch: [0, 4) a spare result block, [8] the index tag
+    uint64_t *tag;  // whose section index the workspace holds (written by the index pass)
     size_t total;
 };
 static ReadWs carve_read_ws(void *base, uint64_t n_vectors, uint64_t n_sections) {
@@ -374,6 +376,7 @@ static ReadWs carve_read_ws(void *base, uint64_t n_vectors, uint64_t n_sections)
     w.sec_res = (uint32_t *)(b + off); off += align_up((n_sections + 1) * 4, 256);
     w.vstatus = (int32_t *)(b + off); off += align_up((n_vectors + 1) * 4, 256);
     w.scan = (uint64_t *)(b + off); off += align_up(scan_scratch_words(n_vectors) * 8, 256);
+    w.tag = w.scan + 8;
     w.total = off;
     return w;
 }
@@ -439,7 +442,7 @@ cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, siz
     // the index pass clears a result block as its side job; here that block is scratch of the workspace
     static_assert(CVEC_RESULT_WORDS * 8 <= 256, "the scan scratch is at least 256 bytes");
     hipError_t e = launch_read(0, READ_INDEX_ONLY, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, w.scan, nullptr,
-                               nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream);
+                               nullptr, nullptr, nullptr, nullptr, w.tag, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_index_dev");
     return CVEC_OK;
 }
@@ -478,7 +481,7 @@ static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, 
     SinkArgs sa;
     memset(&sa, 0, sizeof(sa));
     hipError_t e = launch_read(0, phase, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, d_per_vector, d_status,
-                               d_masks, nullptr, d_gate, (hipStream_t)stream);
+                               d_masks, nullptr, d_gate, w.tag, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_filter_count_dev");
     return CVEC_OK;
 }
@@ -501,7 +504,7 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
         sa.base = batch->etype == CVEC_U64 ? chain->add_const_bits : (chain->add_const_bits & 0xffffffffull);
     }
     hipError_t e = launch_read(1, READ_ALL, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status, nullptr,
-                               d_out, nullptr, (hipStream_t)stream);
+                               d_out, nullptr, w.tag, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_decode_dev");
     return CVEC_OK;
 }

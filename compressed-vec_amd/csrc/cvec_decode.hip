@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
                                                const uint64_t *__restrict__ sec_base, uint64_t n,
                                                uint64_t padded_bytes, const uint8_t *__restrict__ gate,
                                                uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
-                                               uint64_t *__restrict__ result) {
+                                               uint64_t *__restrict__ result, uint64_t *__restrict__ tag,
+                                               uint64_t cookie) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     // One 4-byte load per section header (type byte + 16-bit length), pulled back inside the padded
     // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
@@ -147,6 +148,9 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     };
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v < CVEC_RESULT_WORDS) result[v] = 0; // k_finalize accumulates into it two launches later
+    // Whose index this workspace holds from now on (a gated index is nobody's): a later pass that reuses
+    // the descriptors instead of walking the headers again checks it.
+    if (v == 0) *tag = gate ? 0ull : cookie;
     if (v >= n) return;
     const uint64_t start = byte_off[v], L = byte_off[v + 1] - start;
     const uint64_t slot0 = sec_base[v], nslots = sec_base[v + 1] - slot0;
@@ -608,9 +612,13 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
                                                           uint32_t *__restrict__ sec_res,
-                                                          uint8_t *__restrict__ masks, void *__restrict__ out_) {
+                                                          uint8_t *__restrict__ masks, void *__restrict__ out_,
+                                                          const uint64_t *__restrict__ tag, uint64_t cookie) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared sm;
+    // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
+    // this batch's (k_finalize reports the mismatch); a stale table could point anywhere.
+    if (tag != nullptr && *tag != cookie) return;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -752,19 +760,22 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ s
                                                   const uint32_t *__restrict__ sec_res,
                                                   const int32_t *__restrict__ vstatus,
                                                   uint64_t *__restrict__ per_vec, int32_t *__restrict__ status_out,
-                                                  uint64_t *__restrict__ result) {
+                                                  uint64_t *__restrict__ result, const uint64_t *__restrict__ tag,
+                                                  uint64_t cookie) {
     __shared__ uint64_t s_cnt[4];
     __shared__ uint32_t s_nerr[4], s_max[4];
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t cnt = 0;
     uint32_t st = 0;
+    const bool stale = tag != nullptr && *tag != cookie; // the section pass did not run: see k_sections
     if (v < n) {
-        const uint64_t a = sec_base[v], b = sec_base[v + 1];
+        const uint64_t a = sec_base[v], b = stale ? a : sec_base[v + 1];
         for (uint64_t s = a; s < b; s++) {
             const uint32_t r = sec_res[s];
             if (r >> 16) { st = r >> 16; break; } // the reference's iteration stops at the first failing section
             cnt += r & 0xffffu;
         }
+        if (stale) st = CVEC_ERR_WORKSPACE;
         if (!st) st = (uint32_t)vstatus[v];
         if (per_vec) per_vec[v] = cnt;
         if (status_out) status_out[v] = (int32_t)st;
@@ -870,7 +881,8 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
 // Launches k_sections over a descriptor table (one descriptor per 256-element slot).
 template <int ETYPE>
 static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
-                            const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, hipStream_t stream) {
+                            const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, const uint64_t *tag,
+                            uint64_t cookie, hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).
@@ -891,7 +903,8 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         while (bucket < pb.count) bucket *= 2;
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
-    k_sections<ETYPE, M, N><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out)
+    k_sections<ETYPE, M, N><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, tag, \
+                                                             cookie)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \
     switch (bucket) {                                                                                               \
     case 1: CVEC_LAUNCH_SEC(M, 1); break;                                                                           \
@@ -923,7 +936,7 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     SinkArgs sa;
     memset(&pa, 0, sizeof(pa));
     memset(&sa, 0, sizeof(sa));
-    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, stream);
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, stream);
     return hipGetLastError();
 }
 
@@ -934,43 +947,50 @@ template <int ETYPE>
 static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                           uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
-                          const uint8_t *d_gate, hipStream_t stream) {
+                          const uint8_t *d_gate, uint64_t *tag, hipStream_t stream) {
     const uint64_t n = b.n_vectors, ns = b.n_sections;
+    // identifies the batch whose index the workspace holds: pointers and shape, never zero
+    uint64_t cookie = 0x9e3779b97f4a7c15ull;
+    for (uint64_t x : {(uint64_t)(uintptr_t)b.d_bytes, (uint64_t)(uintptr_t)b.d_byte_off, b.n_bytes, n, ns, (uint64_t)b.etype})
+        cookie = (cookie ^ x) * 0xff51afd7ed558ccdull, cookie ^= cookie >> 29;
+    cookie |= 1;
+    const uint64_t *check = phase == READ_INDEXED ? tag : nullptr;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
     timer_mark(rec, 0, stream);
     if (phase != READ_INDEXED)
         k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
                                                                                      n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
-                                                                                     vstatus, d_result);
+                                                                                     vstatus, d_result, tag, cookie);
     else
         (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream); // k_index does this otherwise
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)
-        launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, stream);
+        launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie, stream);
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,
-                                                                    d_status, d_result);
+                                                                    d_status, d_result, check, cookie);
     timer_mark(rec, 5, stream);
 }
 
 hipError_t launch_read(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                        uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
-                       int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, hipStream_t stream) {
+                       int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, uint64_t *tag,
+                       hipStream_t stream) {
     switch (b.etype) {
     case CVEC_U32:
         launch_read_t<CVEC_U32>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
-                                d_masks, d_out, d_gate, stream);
+                                d_masks, d_out, d_gate, tag, stream);
         break;
     case CVEC_U64:
         launch_read_t<CVEC_U64>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
-                                d_masks, d_out, d_gate, stream);
+                                d_masks, d_out, d_gate, tag, stream);
         break;
     case CVEC_F32:
         launch_read_t<CVEC_F32>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
-                                d_masks, d_out, d_gate, stream);
+                                d_masks, d_out, d_gate, tag, stream);
         break;
     default: return hipErrorInvalidValue;
     }

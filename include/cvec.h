@@ -155,7 +155,11 @@ cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cve
  * that the workspace still holds.  The caller guarantees that the workspace was last written by
  * cvec_index_dev, cvec_filter_count_dev, cvec_filter_count_indexed_dev or cvec_decode_dev on this
  * same batch (an ungated pass: a gated one leaves gated descriptors behind) and that the batch has
- * not changed since.  Results are identical to cvec_filter_count_dev's. */
+ * not changed since.  Results are identical to cvec_filter_count_dev's.  The index pass tags the
+ * workspace with the batch it belongs to (pointers and shape); an indexed call over a workspace that
+ * carries another tag (never indexed, indexed for another batch, last used by a gated pass) follows
+ * no descriptor: every vector reports CVEC_ERR_WORKSPACE and the total is 0.  Changed blob contents
+ * behind the same pointers are not detected. */
 cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, size_t workspace_bytes, void *stream);
 cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
                                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,

@@ -418,6 +418,18 @@ def test_resident_index_gives_the_same_results(cv, oracle):
     # an empty batch
     e = cv.EncodedBatch.from_vectors("u32", []).to_device().build_index()
     assert e.filter_count(3) == 0
+    # a workspace that does not hold this batch's index (never indexed, or indexed for another batch of the
+    # same shape) is refused on the device, not followed: every vector reports the workspace error
+    import torch
+    other = host.to_device().build_index()
+    for ws in (torch.zeros_like(other.workspace()), other.workspace()):
+        stranger = host.to_device()
+        stranger._ws, stranger._keep_index, stranger._index_valid = ws, True, True
+        total, per, st = stranger.filter_count(0, per_vector=True, return_status=True)
+        assert total == 0 and not per.any() and set(st.tolist()) == {104}
+        with pytest.raises(cv.CodingError):
+            stranger.filter_count(0)
+    assert other.filter_count(0, return_status=True)[0] == plain.filter_count(0, return_status=True)[0]   # the owner's index is untouched
 
 
 def test_overwide_shift_octets_take_the_exact_path(cv, oracle):
