@@ -207,7 +207,7 @@ class DeviceBatch:
     def build_index(self):
         """Walks the section headers of every vector once (what each read operation otherwise does as
         its first kernel) and keeps the result in the batch's workspace: from here on ungated filter
-        passes skip that walk.  The batch is immutable, so the index never goes stale; a gated pass
+        and decode passes skip that walk.  The batch is immutable, so the index never goes stale; a gated pass
         overwrites it and the next ungated pass rebuilds it on the way.  All operations of a batch share
         its workspace: enqueue them on one stream (or synchronise between streams)."""
         ws = self.workspace()
@@ -276,8 +276,9 @@ class DeviceBatch:
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
         with torch.cuda.device(self.device):
-            N.check(N.lib().cvec_decode_dev(C.byref(self.view), C.byref(chain), _ptr(out), _ptr(res), _ptr(status),
-                                            _ptr(ws), ws.numel(), _stream_ptr()))
+            fn = N.lib().cvec_decode_indexed_dev if self._keep_index and self._index_valid else N.lib().cvec_decode_dev
+            N.check(fn(C.byref(self.view), C.byref(chain), _ptr(out), _ptr(res), _ptr(status), _ptr(ws), ws.numel(),
+                       _stream_ptr()))
         self._index_valid = True
         return res
 

@@ -486,9 +486,9 @@ static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, 
     return CVEC_OK;
 }
 
-cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
-                            uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
-                            void *stream) {
+static cvec_status decode_phase(int phase, const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
+                                uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
+                                void *stream) {
     cvec_status st = check_view(batch);
     if (st) return st;
     if (!d_result || !d_workspace || (batch->n_sections && !d_out)) return CVEC_ERR_BAD_ARGUMENT;
@@ -503,10 +503,22 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
         sa.add_const = 1;
         sa.base = batch->etype == CVEC_U64 ? chain->add_const_bits : (chain->add_const_bits & 0xffffffffull);
     }
-    hipError_t e = launch_read(1, READ_ALL, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status, nullptr,
-                               d_out, nullptr, w.tag, (hipStream_t)stream);
+    hipError_t e = launch_read(1, phase, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status,
+                               nullptr, d_out, nullptr, w.tag, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_decode_dev");
     return CVEC_OK;
+}
+
+cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
+                            uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
+                            void *stream) {
+    return decode_phase(READ_ALL, batch, chain, d_out, d_result, d_status, d_workspace, workspace_bytes, stream);
+}
+
+cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
+                                    uint64_t *d_result, int32_t *d_status, void *d_workspace,
+                                    size_t workspace_bytes, void *stream) {
+    return decode_phase(READ_INDEXED, batch, chain, d_out, d_result, d_status, d_workspace, workspace_bytes, stream);
 }
 
 static_assert(CVEC_MAX_COLUMNS == CVEC_MAX_PRED_VALUES, "MaskColumns is sized by CVEC_MAX_PRED_VALUES");

@@ -164,6 +164,10 @@ cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, siz
 cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
                                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
                                           void *d_workspace, size_t workspace_bytes, void *stream);
+/* cvec_decode_dev over the resident index, under the same conditions. */
+cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
+                                    uint64_t *d_result, int32_t *d_status, void *d_workspace,
+                                    size_t workspace_bytes, void *stream);
 
 /* VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of the batch.
  * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out (16-byte aligned) holds
