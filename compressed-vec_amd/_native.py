@@ -78,7 +78,8 @@ SIGNATURES = {
                                                 C.c_void_p]),
     "cvec_index_dev": (C.c_int32, [C.POINTER(DBatchView), C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_filter_count_indexed_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
-                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p]),
     "cvec_decode_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(SinkChain), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_decode_indexed_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(SinkChain), C.c_void_p, C.c_void_p,

@@ -207,9 +207,10 @@ class DeviceBatch:
     def build_index(self):
         """Walks the section headers of every vector once (what each read operation otherwise does as
         its first kernel) and keeps the result in the batch's workspace: from here on ungated filter
-        and decode passes skip that walk.  The batch is immutable, so the index never goes stale; a gated pass
-        overwrites it and the next ungated pass rebuilds it on the way.  All operations of a batch share
-        its workspace: enqueue them on one stream (or synchronise between streams)."""
+        and decode passes skip that walk.  The batch is immutable, so the index never goes stale (gated
+        passes over an index read the gate in the section kernel and leave the index as it is).  All
+        operations of a batch share its workspace: enqueue them on one stream (or synchronise between
+        streams)."""
         ws = self.workspace()
         with torch.cuda.device(self.device):
             N.check(N.lib().cvec_index_dev(C.byref(self.view), _ptr(ws), ws.numel(), _stream_ptr()))
@@ -224,8 +225,8 @@ class DeviceBatch:
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
         with torch.cuda.device(self.device):
-            if gate is None and self._keep_index and self._index_valid:
-                N.check(N.lib().cvec_filter_count_indexed_dev(C.byref(self.view), C.byref(p), _ptr(res),
+            if self._keep_index and self._index_valid:
+                N.check(N.lib().cvec_filter_count_indexed_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
                                                               _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
                                                               ws.numel(), _stream_ptr()))
             else:

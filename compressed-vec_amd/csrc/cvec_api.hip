@@ -447,10 +447,10 @@ cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, siz
     return CVEC_OK;
 }
 
-cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
-                                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
-                                          void *d_workspace, size_t workspace_bytes, void *stream) {
-    return filter_count_phase(READ_INDEXED, batch, pred, nullptr, d_result, d_per_vector, d_status, d_masks,
+cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const uint8_t *d_gate,
+                                          uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
+                                          uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return filter_count_phase(READ_INDEXED, batch, pred, d_gate, d_result, d_per_vector, d_status, d_masks,
                               d_workspace, workspace_bytes, stream);
 }
 

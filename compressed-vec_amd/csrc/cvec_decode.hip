@@ -613,7 +613,8 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
                                                           uint32_t *__restrict__ sec_res,
                                                           uint8_t *__restrict__ masks, void *__restrict__ out_,
-                                                          const uint64_t *__restrict__ tag, uint64_t cookie) {
+                                                          const uint64_t *__restrict__ tag, uint64_t cookie,
+                                                          const uint8_t *__restrict__ gate) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared sm;
     // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
@@ -629,8 +630,22 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)data);
     const uint32_t sec = (uint32_t)lane >> 2;
 
+    // `gate` (a pass over a resident index only; otherwise the index pass has applied it already): the
+    // 256-bit mask of the same slot of an earlier column.  Lane q of the quad looks at its quarter; a
+    // section whose gate mask is empty becomes a K_GATED descriptor, as k_index would have made it.
     auto load_desc = [&](uint64_t s) -> uint64_t {
-        return s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
+        uint64_t d = s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
+        if (gate != nullptr) {
+            uint32_t any = 0;
+            if (s + sec < sB) {
+                const uint2 g = *(const uint2 *)(gate + 32 * (s + sec) + 8 * ((uint32_t)lane & 3u));
+                any = g.x | g.y;
+            }
+            any |= __builtin_amdgcn_update_dpp(0u, any, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+            any |= __builtin_amdgcn_update_dpp(0u, any, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
+            if (any == 0 && desc_kind(d) != K_SKIP) d = desc_pack(desc_off(d), 0, K_GATED);
+        }
+        return d;
     };
     auto plan = [&](uint64_t s, uint64_t d) -> ChunkPlan {
         ChunkPlan c;
@@ -882,7 +897,7 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
 template <int ETYPE>
 static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
                             const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, const uint64_t *tag,
-                            uint64_t cookie, hipStream_t stream) {
+                            uint64_t cookie, const uint8_t *d_gate, hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).
@@ -904,7 +919,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     k_sections<ETYPE, M, N><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, tag, \
-                                                             cookie)
+                                                             cookie, d_gate)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \
     switch (bucket) {                                                                                               \
     case 1: CVEC_LAUNCH_SEC(M, 1); break;                                                                           \
@@ -936,7 +951,7 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     SinkArgs sa;
     memset(&pa, 0, sizeof(pa));
     memset(&sa, 0, sizeof(sa));
-    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, stream);
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, stream);
     return hipGetLastError();
 }
 
@@ -966,7 +981,8 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)
-        launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie, stream);
+        launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
+                               phase == READ_INDEXED ? d_gate : nullptr, stream);
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)

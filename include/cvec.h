@@ -155,15 +155,17 @@ cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cve
  * that the workspace still holds.  The caller guarantees that the workspace was last written by
  * cvec_index_dev, cvec_filter_count_dev, cvec_filter_count_indexed_dev or cvec_decode_dev on this
  * same batch (an ungated pass: a gated one leaves gated descriptors behind) and that the batch has
- * not changed since.  Results are identical to cvec_filter_count_dev's.  The index pass tags the
+ * not changed since.  Results are identical to cvec_filter_count_dev's; with d_gate (may be NULL)
+ * they are cvec_filter_count_gated_dev's: the section kernel itself looks at the gate masks, the
+ * index stays the ungated one and remains valid.  The index pass tags the
  * workspace with the batch it belongs to (pointers and shape); an indexed call over a workspace that
  * carries another tag (never indexed, indexed for another batch, last used by a gated pass) follows
  * no descriptor: every vector reports CVEC_ERR_WORKSPACE and the total is 0.  Changed blob contents
  * behind the same pointers are not detected. */
 cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, size_t workspace_bytes, void *stream);
-cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
-                                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
-                                          void *d_workspace, size_t workspace_bytes, void *stream);
+cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const uint8_t *d_gate,
+                                          uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
+                                          uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream);
 /* cvec_decode_dev over the resident index, under the same conditions. */
 cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
                                     uint64_t *d_result, int32_t *d_status, void *d_workspace,

@@ -399,10 +399,14 @@ def test_resident_index_gives_the_same_results(cv, oracle):
             assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), (tname, p)
             w = oracle.batch_filter_count(ET[tname], blob, bo, p)
             assert list(b[2]) == list(w[2]) and np.array_equal(b[1], w[1])
-        # a gated pass in between (gate = all open) leaves gated descriptors behind: the index is rebuilt
+        # a gated pass over the index reads the gate in the section kernel: same masks as the gated full
+        # path, and the index stays as it is
         gate = plain.filter_masks(0)
-        indexed.filter_masks(nz[3], gate=gate)
-        assert not indexed._index_valid
+        g_idx, g_full = indexed.filter_masks(nz[3], gate=gate), plain.filter_masks(nz[3], gate=gate)
+        assert indexed._index_valid and not plain._index_valid
+        assert np.array_equal(g_idx.masks.cpu().numpy(), g_full.masks.cpu().numpy())
+        assert np.array_equal(g_idx.valid.cpu().numpy(), g_full.valid.cpu().numpy())
+        assert np.array_equal(g_idx.result.cpu().numpy(), g_full.result.cpu().numpy())
         a = plain.filter_count(nz[3], per_vector=True, return_status=True)
         b = indexed.filter_count(nz[3], per_vector=True, return_status=True)
         assert indexed._index_valid and a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
@@ -553,6 +557,15 @@ def test_gated_columns_equal_ungated_and_oracle(cv, oracle, tname):
     _, _, st = bad.filter_count(preds[1], per_vector=True, return_status=True)
     if tname != "u64":
         assert st[v] != 0                                          # the plain pass does see it
+    tg, perg = cv.multi_filter([devs[0], bad, devs[2]], preds, per_row=True)
+    assert tg == total and np.array_equal(perg, per_row)
+    # the same columns with resident section indexes: the gate is applied inside the section kernel
+    for d in devs + [bad]:
+        d.build_index()
+    t3, per3, masks3, rows3 = cv.multi_filter(devs, preds, per_row=True, return_masks=True)
+    assert t3 == total and np.array_equal(per3, per_row) and np.array_equal(masks3, masks) and np.array_equal(rows3, rows)
+    g1i = devs[1].filter_masks(preds[1], gate=plain[0])
+    assert np.array_equal(g1i.masks.cpu().numpy(), g1.masks.cpu().numpy())
     tg, perg = cv.multi_filter([devs[0], bad, devs[2]], preds, per_row=True)
     assert tg == total and np.array_equal(perg, per_row)
 

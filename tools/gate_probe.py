@@ -33,6 +33,9 @@ def timed(fn, iters=10):
     return sum(m.value for m in ms) / nrec.value * 1e-3
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "indexed":
+    col.build_index()
+    print("resident section index: the gate is read by the section kernel", flush=True)
 t_plain = timed(lambda: col.filter_count_async(3.0, masks=masks))
 print("masks pass, no gate: %.3f ms  %.0f GB/s" % (t_plain * 1e3, raw / t_plain / 1e9), flush=True)
 g = torch.Generator(device="cuda").manual_seed(1)
