@@ -633,12 +633,15 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     // `gate` (a pass over a resident index only; otherwise the index pass has applied it already): the
     // 256-bit mask of the same slot of an earlier column.  Lane q of the quad looks at its quarter; a
     // section whose gate mask is empty becomes a K_GATED descriptor, as k_index would have made it.
+    // Only the general filter modes take a gate (the launcher sends gated passes there): the count-only
+    // bit-pattern mode and decode keep the pointer out of their loops.
+    const uint8_t *const gate_ = (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) ? gate : nullptr;
     auto load_desc = [&](uint64_t s) -> uint64_t {
         uint64_t d = s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
-        if (gate != nullptr) {
+        if (gate_ != nullptr) {
             uint32_t any = 0;
             if (s + sec < sB) {
-                const uint2 g = *(const uint2 *)(gate + 32 * (s + sec) + 8 * ((uint32_t)lane & 3u));
+                const uint2 g = *(const uint2 *)(gate_ + 32 * (s + sec) + 8 * ((uint32_t)lane & 3u));
                 any = g.x | g.y;
             }
             any |= __builtin_amdgcn_update_dpp(0u, any, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
@@ -934,7 +937,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
             // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN
             const uint32_t fb = (uint32_t)pa.v[0];
             const bool bits_ok = ETYPE != CVEC_F32 || ((fb & 0x7fffffffu) != 0 && (fb & 0x7fffffffu) <= 0x7f800000u);
-            if (bits_ok) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, 1); else CVEC_LAUNCH_SEC(MODE_FILTER, 1);
+            if (bits_ok && !d_gate) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, 1); else CVEC_LAUNCH_SEC(MODE_FILTER, 1);
         } else {
             CVEC_LAUNCH_BUCKET(MODE_FILTER);
         }
