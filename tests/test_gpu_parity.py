@@ -374,6 +374,7 @@ def test_streams_and_columns_randomised_vs_oracle(cv, oracle):
         for kind in ("u64", "u64_delta", "f64_xor"):
             assert fz.streams_round(seed, kind) == [], (seed, kind)
         assert fz.columns_round(seed) == [], seed
+    assert fz.STATS["gated_rounds"] > 10
 
 
 def test_resident_index_gives_the_same_results(cv, oracle):

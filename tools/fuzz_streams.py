@@ -23,6 +23,7 @@ cv = importlib.import_module("compressed-vec_amd")
 import oracle  # noqa: E402
 from fuzz_encode import int_piece  # noqa: E402
 
+STATS = {"gated_rounds": 0}
 PACK = {"u64": oracle.pack_u64, "u64_delta": oracle.pack_u64_delta, "f64_xor": oracle.pack_f64_xor}
 UNPACK = {"u64": oracle.unpack_u64, "u64_delta": oracle.unpack_u64_delta, "f64_xor": oracle.unpack_f64_xor}
 
@@ -130,12 +131,13 @@ def columns_round(seed):
     n = int(rng.integers(1, 30))
     ncol = int(rng.integers(2, 5))
     lens = rng.integers(1, 1800, size=n)
+    ragged = rng.random() < 0.5          # otherwise every column has the same layout and the gated path runs
     blobs = []
     for c in range(ncol):
         vecs = []
         for v in range(n):
             ln = int(lens[v])
-            if c and rng.random() < 0.2:
+            if ragged and c and rng.random() < 0.2:
                 ln = max(1, ln - int(rng.integers(1, 600)))                    # a shorter vector in this column
             x = rng.integers(0, int(rng.integers(2, 5)), size=ln).astype(np.uint32)
             for a in range(0, ln, 256):
@@ -162,9 +164,15 @@ def columns_round(seed):
         errs.append(("total", int(total), want_total))
     same_layout = all(np.array_equal(d.d_sec_base.cpu().numpy(), sb0) for d in devs)
     if same_layout:                                                            # the gated path needs equal layouts
-        t2, per2 = cv.multi_filter(devs, preds, per_row=True)
-        if t2 != total or not np.array_equal(per2, per_row):
+        t2, per2, m2, r2 = cv.multi_filter(devs, preds, per_row=True, return_masks=True)
+        if t2 != total or not np.array_equal(per2, per_row) or not np.array_equal(m2, masks) or not np.array_equal(r2, rows):
             errs.append(("gated differs",))
+        for d in devs:                                                         # and over resident section indexes
+            d.build_index()
+        t3, per3, m3, r3 = cv.multi_filter(devs, preds, per_row=True, return_masks=True)
+        if t3 != total or not np.array_equal(per3, per_row) or not np.array_equal(m3, masks) or not np.array_equal(r3, rows):
+            errs.append(("gated over index differs",))
+        STATS["gated_rounds"] += 1
     return errs
 
 
@@ -188,7 +196,7 @@ def main():
         if time.time() - last > 20:
             last = time.time()
             print("progress: rounds", rounds, "mismatches", bad, flush=True)
-    print("stream/column fuzz done: rounds", rounds, "mismatches", bad, flush=True)
+    print("stream/column fuzz done: rounds", rounds, "mismatches", bad, STATS, flush=True)
     sys.exit(1 if bad else 0)
 
 
