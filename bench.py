@@ -247,8 +247,9 @@ def main():
     achieved = raw_bytes / (k_sections_ms * 1e-3) / 1e9
 
     out = {
-        "metric": "device-resident decode+filter GB/s (uncompressed bytes), f32 XOR",
-        "value": round(value, 2),
+        "metric": "device-resident decode+filter GB/s (uncompressed bytes) per GPU and node, f32 XOR",
+        "value": round(value, 2),                 # the node: all ranks together
+        "value_per_gpu": round(value / world, 2),
         "unit": "GB/s",
         "n_gpus": world,
         "steps": args.steps,
