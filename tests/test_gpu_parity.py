@@ -814,6 +814,42 @@ def test_resident_batch_grows_by_appended_vectors(cv, oracle):
     assert rc == 0 and np.array_equal(dec, want)
 
 
+@pytest.mark.parametrize("name", ["u32 dense", "u32 sparse", "f32 xor 60%", "u64 delta"])
+def test_reference_bench_configurations_vs_oracle(cv, oracle, name):
+    """The reference's `cargo bench vector` workloads (benches/bench.rs:131-170: 10000-element vectors;
+    dense u32 sinusoid, the same with all but two runs of 50 values nulled, f32 at 60 % density / 1.4,
+    u64 = dense + 100000) at a size the oracle finishes in seconds: encoded bytes, filter + count,
+    decode through AddConstSink -> VecSink and the encode_all -> decode round trip against the oracle."""
+    from compressed_vec_amd import synth
+    nvec, length = 48, synth.VECTOR_LENGTH
+    tname, kind, pred, base = {"u32 dense": ("u32", "u32_dense", 3, 7), "u32 sparse": ("u32", "u32_dense", 15, 7),
+                               "f32 xor 60%": ("f32", "f32_xor", np.float32(3) / np.float32(1.4), 2.5),
+                               "u64 delta": ("u64", "u64_delta", 100003, 5)}[name]
+    vals, eo = synth.batch_values(kind, nvec, length)
+    if name == "u32 sparse":                                    # benches/bench.rs:160-170
+        keep = np.zeros(length, dtype=bool)
+        keep[2475:2525] = keep[7475:7525] = True
+        vals = np.where(np.tile(keep, nvec), vals, 0).astype(np.uint32)
+    want_blob, want_off = oracle.batch_encode(ET[tname], vals, eo)
+    got = cv.encode_batch(tname, vals, eo)
+    assert np.array_equal(got.byte_off, want_off) and np.array_equal(got.blob, want_blob)
+    dev = got.to_device()
+    total, per = dev.filter_count(pred, per_vector=True)
+    wtotal, wper, wst, rc = oracle.batch_filter_count(ET[tname], want_blob, want_off, pred)
+    assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+    assert total == int((vals == NPD[tname](pred)).sum())       # 10000 = 39 sections + 16 elements: the padding is zero
+    dec, off = dev.decode(add_const=base)
+    wdec, _, rc = oracle.batch_decode(ET[tname], want_blob, want_off, off, add_base=base)
+    assert rc == 0 and np.array_equal(_bits(dec), _bits(wdec))
+    plain, _ = dev.decode()
+    for v in (0, nvec // 2, nvec - 1):
+        a = plain[int(off[v]):int(off[v]) + length]
+        assert np.array_equal(_bits(a), _bits(vals[v * length:(v + 1) * length]))
+    if name == "u32 sparse":
+        kinds = oracle.reader_sections(ET[tname], want_blob[int(want_off[0]):int(want_off[1])])
+        assert (kinds == 0).sum() >= 36                         # Null sections: the short-circuit path
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
