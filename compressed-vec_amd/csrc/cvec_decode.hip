@@ -245,11 +245,16 @@ constexpr int TILE = 16; // sections per chunk: one per quad of lanes
 // Staging region of one wave: 18 KiB = 18 wave-wide 16-byte loads / LDS writes of 1 KiB; holds 16 worst-case
 // u32/f32 sections (1100 B) plus the vector headers between them.  Four waves per workgroup, two
 // workgroups per CU: 144 of the CU's 160 KiB.
+// A second shape, 12 KiB regions at three workgroups per CU, serves count-only passes over batches whose
+// sections are small enough that 16 of them still fit (dense integers, deltas): the octet loop is bound
+// by VALU issue, and a third wave per SIMD fills the slots that two leave empty (u32 dense 0.180 ->
+// 0.159 ms per GiB); 16 incompressible f32 sections do not fit 12 KiB and lose more lanes than that gains.
 constexpr int REGION_PIECES = 18;
-constexpr uint32_t REGION_BYTES = REGION_PIECES * 1024;
+constexpr int REGION_PIECES_SMALL = 12;
+
 // The last 64 bytes of a region stay zero: sections without octets (Null, Const, skipped slots) run
 // the octet loop over them (32 empty octets), which keeps the loop free of per-kind masking.
-constexpr uint32_t REGION_SPAN = REGION_BYTES - 64;
+constexpr uint32_t region_span(int pieces) { return (uint32_t)pieces * 1024u - 64u; }
 constexpr int SEC_WAVES = 4;
 constexpr int SEC_THREADS = SEC_WAVES * 64;
 
@@ -257,8 +262,9 @@ constexpr int SEC_THREADS = SEC_WAVES * 64;
 // patterns (any integer; a float that is neither zero nor NaN): matching needs no compare instruction.
 enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2, MODE_FILTER_BITS = 3 };
 
+template <int PIECES>
 struct SecShared {
-    __attribute__((aligned(16))) uint8_t data[SEC_WAVES][REGION_BYTES];
+    __attribute__((aligned(16))) uint8_t data[SEC_WAVES][PIECES * 1024];
 };
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
@@ -333,7 +339,7 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
 // more than 8 nibbles or 8 or more trailing zero nibbles (never produced by an encoder: the value
 // would not fit 32 bits) and only records whether one did; the caller then repeats the chunk with
 // CAREFUL = true, which handles both exactly.  Returns that record.
-template <int ETYPE, int MODE, int NPRED, bool CAREFUL>
+template <int ETYPE, int MODE, int NPRED, bool CAREFUL, int PIECES>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
@@ -345,7 +351,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     const bool isconst = live && kind == K_CONST, isdelta = live && kind == K_DELTA;
     const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
     const uint32_t end = rel + len;
-    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : (kind == K_RAW ? 0u : 3u)) : REGION_SPAN;
+    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : (kind == K_RAW ? 0u : 3u)) : region_span(PIECES);
     // Const value (section byte 1) or Delta base (section byte 4)
     U v = 0;
     if (isconst || isdelta) v = lds_load_unaligned<W>(lds_base + rel + (isconst ? 1u : 4u));
@@ -607,8 +613,8 @@ struct ChunkPlan {
 // (process_chunk) while the loads fly.  Registers, not a second LDS region, double-buffer the
 // stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
 // No barriers and no cross-wave traffic.
-template <int ETYPE, int MODE, int NPRED>
-__global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__restrict__ bytes,
+template <int ETYPE, int MODE, int NPRED, int PIECES>
+__global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
                                                           uint32_t *__restrict__ sec_res,
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                                                           const uint64_t *__restrict__ tag, uint64_t cookie,
                                                           const uint8_t *__restrict__ gate) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
-    __shared__ SecShared sm;
+    __shared__ SecShared<PIECES> sm;
     // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
     // this batch's (k_finalize reports the mismatch); a stale table could point anywhere.
     if (tag != nullptr && *tag != cookie) return;
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         uint32_t len = desc_len(d);
         c.len = len < SectLimits<W>::MAX_BYTES ? len : SectLimits<W>::MAX_BYTES;
         const uint64_t endl = off + c.len - c.gb; // wraps to a huge value if off < gb
-        const bool fits = !wants || endl <= (uint64_t)REGION_SPAN;
+        const bool fits = !wants || endl <= (uint64_t)region_span(PIECES);
         const unsigned long long m = __ballot(fits);
         uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> 2;
         c.n = n < avail ? n : avail;
@@ -683,16 +689,16 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
     // descriptor over exactly the span, so lanes past its end cost no traffic and return zeros;
     // the whole region (zero pad included) is rewritten for every chunk without any per-lane test.
     typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
-    u32x4 R[REGION_PIECES];
+    u32x4 R[PIECES];
     auto issue_loads = [&](const ChunkPlan &c) {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)(sa._pad == 5 ? 0u : c.nch * 16u), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < REGION_PIECES; i++)
+        for (int i = 0; i < PIECES; i++)
             R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 2 /* nt: read once */);
     };
 
 #pragma unroll
-    for (int i = 0; i < REGION_PIECES; i++) R[i] = u32x4{0, 0, 0, 0};
+    for (int i = 0; i < PIECES; i++) R[i] = u32x4{0, 0, 0, 0};
     // The first pass of the loop has an empty current chunk: it only plans and loads chunk 0.
     uint64_t s_cur = sA;
     ChunkPlan cur;
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
         {
             u32x4 *dst = (u32x4 *)data;
 #pragma unroll
-            for (int i = 0; i < REGION_PIECES; i++) dst[64 * i + lane] = R[i];
+            for (int i = 0; i < PIECES; i++) dst[64 * i + lane] = R[i];
         }
         __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
         if (res_pending) sec_res[res_slot] = res_word;
@@ -748,11 +754,11 @@ __global__ __launch_bounds__(SEC_THREADS, 2) void k_sections(const uint8_t *__re
                 mk_pending = cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
             }
         } else if (cur.n != 0 && sa._pad != 1) {
-            const bool odd = process_chunk<ETYPE, MODE, NPRED, false>(data, lds_base, cur.kind, cur.rel, cur.len,
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, false, PIECES>(data, lds_base, cur.kind, cur.rel, cur.len,
                                                                       sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
                                                                       mk_lo, mk_hi, out_);
             if (__ballot(odd) != 0)
-                process_chunk<ETYPE, MODE, NPRED, true>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
+                process_chunk<ETYPE, MODE, NPRED, true, PIECES>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
                                                         s_cur + sec, lane, pa, sa, res_word, mk_lo, mk_hi, out_);
             res_slot = s_cur + sec;
             res_pending = sec < cur.n && (lane & 3) == 0;
@@ -900,12 +906,20 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
 template <int ETYPE>
 static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
                             const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, const uint64_t *tag,
-                            uint64_t cookie, const uint8_t *d_gate, hipStream_t stream) {
+                            uint64_t cookie, const uint8_t *d_gate, uint64_t n_bytes, hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
-        // range of section slots (a multiple of TILE).
+        // range of section slots (a multiple of TILE).  Count-only passes over a batch whose average
+        // section is small enough for 16 of them to fit a 12 KiB region run 3 workgroups per CU on such
+        // regions (n_bytes == 0: size unknown, the large shape).
         static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 1; }();
-        static const int wgcu = [] { const char *e = getenv("CVEC_WG_PER_CU"); return e ? atoi(e) : 2; }();
+        static const int wgcu_env = [] { const char *e = getenv("CVEC_WG_PER_CU"); return e ? atoi(e) : 0; }();
+        static const int shape_env = [] { const char *e = getenv("CVEC_REGION_SHAPE"); return e ? atoi(e) : 0; }(); // 1 = always large, 2 = small where possible
+        const bool count_only = mode != MODE_DECODE && d_masks == nullptr;
+        bool small = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL);
+        if (shape_env == 1) small = false;
+        if (shape_env == 2) small = count_only;
+        const int wgcu = wgcu_env > 0 ? wgcu_env : (small ? 3 : 2);
         const uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
         uint64_t per = (ns + nwaves_max - 1) / nwaves_max;
         per = (per + TILE - 1) / TILE * TILE;
@@ -920,9 +934,14 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         uint32_t bucket = 1;
         while (bucket < pb.count) bucket *= 2;
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
+#define CVEC_LAUNCH_SEC_P(M, N, P)                                                                                  \
+    k_sections<ETYPE, M, N, P><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
+                                                                tag, cookie, d_gate)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
-    k_sections<ETYPE, M, N><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, tag, \
-                                                             cookie, d_gate)
+    do {                                                                                                            \
+        if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES_SMALL);     \
+        else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES);                                                                \
+    } while (0)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \
     switch (bucket) {                                                                                               \
     case 1: CVEC_LAUNCH_SEC(M, 1); break;                                                                           \
@@ -943,6 +962,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         }
 #undef CVEC_LAUNCH_BUCKET
 #undef CVEC_LAUNCH_SEC
+#undef CVEC_LAUNCH_SEC_P
     }
 }
 
@@ -954,7 +974,7 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     SinkArgs sa;
     memset(&pa, 0, sizeof(pa));
     memset(&sa, 0, sizeof(sa));
-    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, stream);
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, stream);
     return hipGetLastError();
 }
 
@@ -985,7 +1005,7 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)
         launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
-                               phase == READ_INDEXED ? d_gate : nullptr, stream);
+                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, stream);
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)

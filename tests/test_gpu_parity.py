@@ -850,6 +850,28 @@ def test_reference_bench_configurations_vs_oracle(cv, oracle, name):
         assert (kinds == 0).sum() >= 36                         # Null sections: the short-circuit path
 
 
+def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle):
+    """Count-only passes pick 12 KiB staging regions (three workgroups per CU) when 16 average sections fit
+    them, 18 KiB ones otherwise; a batch of small sections with a few vectors of incompressible ones mixed
+    in runs the small shape with chunks that break early, and must count like the oracle either way."""
+    rng = np.random.default_rng(77)
+    small = [rng.integers(1, 200, size=int(rng.integers(200, 3000))).astype(np.uint32) for _ in range(300)]
+    big = [rng.integers(0, 1 << 32, size=2048, dtype=np.uint64).astype(np.uint32) for _ in range(6)]
+    vecs = small[:100] + big[:3] + small[100:] + big[3:]
+    eo = np.concatenate([[0], np.cumsum([v.size for v in vecs])]).astype(np.uint64)
+    vals = np.concatenate(vecs)
+    blob, bo = oracle.batch_encode(oracle.U32, vals, eo)
+    dev = cv.EncodedBatch("u32", blob, bo).to_device()
+    assert dev.n_bytes / dev.n_sections < 700                  # the launcher's rule picks the small shape
+    for p in (7, [7, 9, 150], int(big[0][5])):
+        total, per = dev.filter_count(p, per_vector=True)
+        wtotal, wper, _, rc = oracle.batch_filter_count(oracle.U32, blob, bo, p)
+        assert rc == 0 and total == wtotal and np.array_equal(per, wper), p
+    onlybig = cv.encode_batch("u32", np.concatenate(big), np.arange(7, dtype=np.uint64) * 2048).to_device()
+    assert onlybig.n_bytes / onlybig.n_sections > 1000         # the large shape
+    assert onlybig.filter_count(int(big[1][9])) == int((np.concatenate(big) == big[1][9]).sum())
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
