@@ -121,6 +121,7 @@ class DeviceBatch:
         self.view = v
         self._ws = None
         self._result = None
+        self._layout_sig = None
         self._keep_index = False    # build_index() was called: ungated filters reuse the section index
         self._index_valid = False   # the workspace holds the ungated index of this batch
 
@@ -189,6 +190,19 @@ class DeviceBatch:
             nbytes = N.lib().cvec_workspace_bytes(self.n_vectors, self.n_sections)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def layout_signature(self):
+        """A number that two batches share iff their vectors have the same section counts (sec_base equal):
+        computed on the device once per batch, so that comparing layouts costs no synchronisation later."""
+        if self._layout_sig is None:
+            sb = self.d_sec_base
+            idx = torch.arange(1, sb.numel() + 1, device=sb.device, dtype=torch.int64)
+            # position-weighted wrapping sums with two odd multipliers: equal arrays give equal sums, and two
+            # different monotone arrays of the same length and total do not collide in practice
+            a = int((sb * (idx * 0x9E3779B1 + 1)).sum().item())
+            b = int(((sb ^ (sb >> 7)) * (idx * 0x85EBCA77 + 3)).sum().item())
+            self._layout_sig = (self.n_vectors, self.n_sections, a, b)
+        return self._layout_sig
 
     def result_buffer(self):
         if self._result is None:
@@ -260,7 +274,7 @@ class DeviceBatch:
         masks = torch.zeros(self.n_sections * 32, dtype=torch.uint8, device=self.device)
         g = None
         if gate is not None and gate.batch.n_sections == self.n_sections and \
-                torch.equal(gate.batch.d_sec_base, self.d_sec_base):
+                gate.batch.n_vectors == self.n_vectors and gate.batch.layout_signature() == self.layout_signature():
             g = gate.masks
         res = self.filter_count_async(pred, masks=masks, gate=g)
         valid = torch.empty(max(self.n_vectors, 1), dtype=torch.int32, device=self.device)
