@@ -367,14 +367,16 @@ def test_encoder_on_adversarial_values_vs_oracle(cv, oracle):
 
 
 def test_streams_and_columns_randomised_vs_oracle(cv, oracle):
-    """Stream codecs on adversarial values and on damaged or cut packed bytes, and the multi-column filter
-    over columns whose vectors differ in length, against the oracle."""
+    """Stream codecs on adversarial values and on damaged or cut packed bytes, the multi-column filter over
+    columns whose vectors differ in length, and series of histograms (some damaged) through the
+    delta-diff re-packer, against the oracle."""
     fz = _tool("fuzz_streams")
     for seed in range(9000, 9060):
         for kind in ("u64", "u64_delta", "f64_xor"):
             assert fz.streams_round(seed, kind) == [], (seed, kind)
         assert fz.columns_round(seed) == [], seed
-    assert fz.STATS["gated_rounds"] > 10
+        assert fz.hist_round(seed) == [], seed
+    assert fz.STATS["gated_rounds"] > 10 and fz.STATS["hist_failed"] > 10
 
 
 def test_resident_index_gives_the_same_results(cv, oracle):

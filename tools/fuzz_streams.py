@@ -5,6 +5,7 @@ Streams: ragged batches of adversarial values; packed bytes and unpacked values 
 then the packed bytes are damaged and cut, and every stream must fail exactly when the oracle fails and
 give the oracle's values when it does not.  Columns: two to four columns of ragged u32 vectors with
 section-aligned and unaligned length differences; totals, per-row counts and masks against the oracle.
+Histograms: random series through DeltaDiffPackSink, some packed histograms damaged or cut.
 Usage: python tools/fuzz_streams.py [--seconds 60] [--seed0 0]
 """
 import argparse
@@ -176,6 +177,62 @@ def columns_round(seed):
     return errs
 
 
+def hist_round(seed):
+    """DeltaDiffPackSink over random series of histograms (src/histogram.rs:92-171), some of them damaged or
+    cut: outputs, value_dropped and which histograms fail (a failure takes the rest of its series along)."""
+    rng = np.random.default_rng(seed)
+    hist = cv.histogram
+    nb = int(rng.integers(1, 600))
+    lens = [int(rng.integers(0, 7)) for _ in range(int(rng.integers(1, 6)))]
+    series_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    packed = []
+    for ln in lens:
+        counts = np.zeros(nb, dtype=np.uint64)
+        for _ in range(ln):
+            counts = counts + rng.integers(0, 1 << int(rng.integers(1, 50)), nb).astype(np.uint64) * (rng.random(nb) < 0.6)
+            if rng.random() < 0.25:
+                counts[rng.integers(0, nb)] = 0
+            vals = counts if rng.random() < 0.3 else np.diff(np.concatenate([[0], np.sort(counts)])).astype(np.uint64)
+            b = bytearray(oracle.pack_u64(vals))
+            how = rng.random()
+            if how < 0.08 and len(b) > 1:
+                b = b[:int(rng.integers(0, len(b)))]
+            elif how < 0.16:
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            packed.append(bytes(b))
+    if not packed or sum(len(p) for p in packed) == 0:
+        return []
+    want_out, want_drop, want_fail = [], [], []
+    h = 0
+    for ln in lens:
+        osink = oracle.DeltaDiffPackSink(nb)
+        failed = False
+        for _ in range(ln):
+            if not failed:
+                try:
+                    o, dr, _ = osink.feed(packed[h])
+                except oracle.OracleError:
+                    failed = True
+            want_fail.append(failed)
+            want_out.append(b"" if failed else o)
+            want_drop.append(False if failed else dr)
+            h += 1
+    off = np.concatenate([[0], np.cumsum([len(p) for p in packed])]).astype(np.uint64)
+    blob = np.frombuffer(b"".join(packed), dtype=np.uint8).copy()
+    out, oo, dropped, st = hist.delta_diff_batch(blob, off, series_off, nb)
+    errs = []
+    for i in range(len(packed)):
+        if (st[i] != 0) != want_fail[i]:
+            errs.append(("hist status", i, int(st[i]), want_fail[i], nb))
+        elif not want_fail[i]:
+            if out[int(oo[i]):int(oo[i + 1])].tobytes() != want_out[i]:
+                errs.append(("hist bytes", i, nb))
+            elif bool(dropped[i]) != want_drop[i]:
+                errs.append(("hist dropped", i, nb))
+    STATS["hist_failed"] = STATS.get("hist_failed", 0) + sum(want_fail)
+    return errs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
@@ -191,7 +248,10 @@ def main():
         for e in columns_round(seed):
             bad += 1
             print("MISMATCH seed", seed, "columns", e, flush=True)
-        rounds += 4
+        for e in hist_round(seed):
+            bad += 1
+            print("MISMATCH seed", seed, "histograms", e, flush=True)
+        rounds += 5
         seed += 1
         if time.time() - last > 20:
             last = time.time()
