@@ -364,6 +364,7 @@ def test_encoder_on_adversarial_values_vs_oracle(cv, oracle):
     for seed in range(7000, 7100):
         for tname in ("u32", "u64", "f32"):
             assert fz.one_round(seed, tname)[0] == [], (seed, tname)
+            assert fz.appender_round(seed, tname) == [], (seed, tname)   # append / append_nulls / reader / finish
 
 
 def test_streams_and_columns_randomised_vs_oracle(cv, oracle):

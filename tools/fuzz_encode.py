@@ -3,7 +3,8 @@ integer range, ranges whose max - min needs every bit, values with chosen leadin
 NaN payloads, signed zeros, infinities, denormals and raw random bit patterns.
 
 For every seed and element type the device-encoded bytes and offsets must equal the oracle's, and the
-device decode of them must equal the oracle's decode bit for bit.
+device decode of them must equal the oracle's decode bit for bit.  Each seed also drives the appender
+mirror and the oracle's appender through the same random append / append_nulls / reader / finish calls.
 Usage: python tools/fuzz_encode.py [--seconds 60] [--seed0 0]
 """
 import argparse
@@ -143,6 +144,48 @@ def one_round(seed, tname):
     return errs, int(vals.size)
 
 
+APPENDER = {"u32": "VectorU32Appender", "u64": "VectorU64Appender", "f32": "VectorF32XorAppender"}
+
+
+def appender_round(seed, tname):
+    """A random sequence of append / append_many / append_nulls on the appender mirror and on the oracle's
+    appender (src/vector.rs:207-379), a look through reader() on the way, then finish() with as many rows as
+    appended or more: same bytes, null-section count included."""
+    rng = np.random.default_rng(seed)
+    a = getattr(cv, APPENDER[tname]).try_new(int(rng.integers(8, 4096)))
+    o = oracle.Appender(ET[tname], 4096)
+    errs = []
+    for _ in range(int(rng.integers(0, 12))):
+        op = int(rng.integers(0, 4))
+        if op == 0:
+            k = int(rng.integers(1, 700))
+            v = f32_piece(rng, k).view(np.float32) if tname == "f32" else \
+                int_piece(rng, k, 32 if tname == "u32" else 64).astype(NPD[tname])
+            a.append_many(v)
+            o.append_many(v)
+        elif op == 1:
+            v = NPD[tname](rng.integers(0, 1000))
+            a.append(v)
+            o.append(v)
+        elif op == 2:
+            n = int(rng.integers(0, 900))
+            a.append_nulls(n)
+            o.append_nulls(n)
+        else:
+            r = a.reader()
+            w = cv.VectorReader.try_new(o.reader_bytes(), tname)
+            if r.num_elements() != w.num_elements() or r.get_stats() != w.get_stats():
+                errs.append(("reader", r.get_stats(), w.get_stats()))
+            elif not np.array_equal(bits_of(r.iterate()), bits_of(w.iterate())):
+                errs.append(("reader values",))
+        if a.num_elements() != o.num_elements():
+            errs.append(("num_elements", a.num_elements(), o.num_elements()))
+    total = a.num_elements() + (int(rng.integers(0, 1500)) if rng.random() < 0.4 else 0)
+    if a.finish(total) != o.finish(total):
+        errs.append(("finish bytes", total))
+    return errs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60)
@@ -158,6 +201,9 @@ def main():
             for e in errs:
                 bad += 1
                 print("MISMATCH seed", seed, tname, e, flush=True)
+            for e in appender_round(seed, tname):
+                bad += 1
+                print("MISMATCH seed", seed, tname, "appender", e, flush=True)
         seed += 1
         if time.time() - last > 20:
             last = time.time()
