@@ -83,3 +83,26 @@ def splitmix_f32_torch(n_vectors, length, device="cuda", v_first=0, mantissa_bit
     bits = (frac | 0x3F800000).to(torch.int32)
     elem_off = torch.arange(n_vectors + 1, device=device, dtype=torch.int64) * length
     return bits.view(torch.float32).reshape(-1).contiguous(), elem_off
+
+
+def splitmix_f32(n_vectors, length, v_first=0, mantissa_bits=12):
+    """splitmix_f32_torch on the host with numpy (same bits): (values float32, elem_off uint64)."""
+    with np.errstate(over="ignore"):
+        seed = (np.arange(n_vectors, dtype=np.uint64)[:, None] + np.uint64(0xC0FFEE + v_first))
+        idx = np.arange(1, length + 1, dtype=np.uint64)[None, :]
+        z = seed + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    frac = (z & np.uint64((1 << mantissa_bits) - 1)) << np.uint64(23 - mantissa_bits)
+    bits = (frac | np.uint64(0x3F800000)).astype(np.uint32)
+    elem_off = np.arange(n_vectors + 1, dtype=np.uint64) * np.uint64(length)
+    return bits.view(np.float32).reshape(-1).copy(), elem_off
+
+
+def sparse_u32_vector_parts():
+    """The pieces of the reference's very sparse u32 vector (benches/bench.rs:160-170): explicit null
+    runs and two runs of 50 sinusoid values; finish(10000).  Returns the list of ('nulls', n) /
+    ('values', array) steps an appender is driven with, and the row count for finish()."""
+    nonzeroes = sinewave_varnonzeros_u32(1.0, 50)
+    return [("nulls", 2475), ("values", nonzeroes), ("nulls", 4950), ("values", nonzeroes)], VECTOR_LENGTH

@@ -453,3 +453,42 @@ def batch_decode(etype, blob, byte_off, out_off, add_base=None):
     rc = lib().ocv_batch_decode(etype, _ptr(b), _ptr(bo), n, int(add_base is not None), _ptr(base), _ptr(out),
                                 _ptr(oo), _ptr(st))
     return out, st, rc
+
+
+class ref_tail_quirk:
+    """with oracle.ref_tail_quirk(): ...  decodes the way the reference's tail fallback does
+    (nibblepack_simd.rs:433-450, :546-554: zeros for a 5..8-nibble octet with fewer than 34 bytes left
+    in the vector slice).  Documentation only: nothing compares the GPU with this mode."""
+
+    def __enter__(self):
+        lib().ocv_set_ref_tail_quirk(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ocv_set_ref_tail_quirk(0)
+        return False
+
+
+def tail_quirk_census(etype, blob, byte_off, pred=None):
+    """How far the reference crate's decoder (tail fallback bug included) would differ from the wire
+    format's plain bitstream rule on this batch: (vectors whose decoded values differ, decoded
+    elements that differ, filter-count difference for `pred` or None)."""
+    bo = np.ascontiguousarray(byte_off, dtype=np.uint64)
+    n = bo.size - 1
+    nsec = np.zeros(n + 1, dtype=np.uint64)
+    for v in range(n):
+        ne = int(np.frombuffer(blob[int(bo[v]) + 8:int(bo[v]) + 12].tobytes(), dtype="<u4")[0])
+        nsec[v + 1] = nsec[v] + np.uint64((ne + 255) // 256 * 256)
+    good, st, rc = batch_decode(etype, blob, bo, nsec)
+    assert rc == 0
+    with ref_tail_quirk():
+        bad, st, rc = batch_decode(etype, blob, bo, nsec)
+        assert rc == 0
+        cq = batch_filter_count(etype, blob, bo, pred)[0] if pred is not None else None
+    bits = np.uint64 if etype == U64 else np.uint32
+    diff = good.view(bits) != bad.view(bits)
+    per_vec = np.add.reduceat(diff.astype(np.int64), nsec[:-1].astype(np.int64)) if n else np.zeros(0, dtype=np.int64)
+    dc = None
+    if pred is not None:
+        dc = int(cq) - int(batch_filter_count(etype, blob, bo, pred)[0])
+    return int((per_vec > 0).sum()), int(diff.sum()), dc

@@ -15,7 +15,14 @@
 #define DELTA_HDR 12             /* section.rs:607 */
 #define GROW_BYTES 4096          /* vector.rs:188 */
 
+/* Documentation mode: decode the way the reference's tail fallback does (nibblepack_simd.rs:433-450
+ * returns zeros for a 5..8-nibble octet when fewer than 34 bytes are left in the slice it is handed,
+ * :546-554).  That slice is the rest of the whole VECTOR slice, not of the section: the section
+ * readers keep `sect_bytes` = everything from the section's type byte to the end of the bytes given to
+ * VectorReader::try_new (section.rs:548, :636, :706; vector.rs:443, :448).  t_slice_tail = bytes of
+ * that slice behind the section being decoded (0 for calls that are handed a bare section or octet). */
 static int g_ref_tail_quirk = 0;
+static _Thread_local size_t t_slice_tail = 0;
 void ocv_set_ref_tail_quirk(int on) { g_ref_tail_quirk = on; }
 
 /* ---------- L0: little-endian byte IO (byteutils.rs:9-48) ---------- */
@@ -124,7 +131,7 @@ int ocv_unpack8_u32(const uint8_t *in, size_t len, uint32_t out[8], int *zeroes,
     unsigned cnt = (unsigned)popcount8(mask);
     size_t nbytes = ((size_t)n * cnt + 1) / 2;                    /* :534,:543,:547 */
     if (2 + nbytes > len) return OCV_NOT_ENOUGH_SPACE;            /* reference: panic at :565 */
-    int drop = g_ref_tail_quirk && n >= 5 && len < 34;            /* :546-554 + :433-450 */
+    int drop = g_ref_tail_quirk && n >= 5 && len + t_slice_tail < 34;   /* :546-554 + :433-450 */
     unsigned idx = 0;
     for (int j = 0; j < 8; j++) {
         if (mask & (1u << j)) {
@@ -647,7 +654,15 @@ static int decode_octets_int(int etype, const uint8_t *p, size_t len, sink *out)
 
 /* FixedSectEnum::decode → FSUtils::decode_to_sink (section.rs:237-240, :317-326, :348-357, :379-387).
  * `in` points at the section type byte, nb = its num_bytes() (already parsed). */
-static int section_decode_to(int etype, int kind, const uint8_t *in, size_t nb, sink *out) {
+static int section_decode_body(int etype, int kind, const uint8_t *in, size_t nb, sink *out);
+/* slice_tail: bytes of the vector slice behind this section (only the tail-quirk mode looks at it). */
+static int section_decode_to(int etype, int kind, const uint8_t *in, size_t nb, size_t slice_tail, sink *out) {
+    t_slice_tail = slice_tail;
+    int rc = section_decode_body(etype, kind, in, nb, out);
+    t_slice_tail = 0;
+    return rc;
+}
+static int section_decode_body(int etype, int kind, const uint8_t *in, size_t nb, sink *out) {
     int w = elem_width(etype);
     if (kind == OCV_SECT_NULL) {                                  /* :454-460 */
         for (int k = 0; k < FIXED_LEN / 8; k++) out->process_zeroes(out);
@@ -688,7 +703,7 @@ int ocv_section_decode(int etype, const uint8_t *in, size_t len, void *out256) {
     if (rc) return rc;
     s256_sink s;
     s256_init(&s, elem_width(etype));
-    rc = section_decode_to(etype, kind, in, nb, &s.s);
+    rc = section_decode_to(etype, kind, in, nb, len - nb, &s.s);
     if (rc) return rc;
     memcpy(out256, s.values, FIXED_LEN * (size_t)elem_width(etype));
     return OCV_OK;
@@ -886,7 +901,7 @@ static int decode_vector_to(int etype, const uint8_t *bytes, size_t len, sink *o
         int kind; size_t nb;
         rc = ocv_section_parse(etype, bytes + pos, len - pos, &kind, &nb);
         if (rc) return rc;
-        rc = section_decode_to(etype, kind, bytes + pos, nb, out);
+        rc = section_decode_to(etype, kind, bytes + pos, nb, len - pos - nb, out);
         if (rc) return rc;
         pos += nb;
     }
@@ -922,7 +937,7 @@ int ocv_iterate(int etype, const uint8_t *bytes, size_t len, void *out, size_t o
             if (pos < len) {
                 int kind; size_t nb;
                 if (ocv_section_parse(etype, bytes + pos, len - pos, &kind, &nb) == OCV_OK) {
-                    rc = section_decode_to(etype, kind, bytes + pos, nb, &s.s);
+                    rc = section_decode_to(etype, kind, bytes + pos, nb, len - pos - nb, &s.s);
                     if (rc) return rc;                            /* reference: expect() panic */
                     pos += nb;
                 }
@@ -958,7 +973,7 @@ static int vfilter_next(vfilter *f, uint8_t mask[32], int *err) {
         return 1;
     }
     f->fs.s.reset(&f->fs.s);
-    rc = section_decode_to(f->etype, kind, sect, nb, &f->fs.s);
+    rc = section_decode_to(f->etype, kind, sect, nb, f->len - f->pos, &f->fs.s);
     if (rc) { *err = rc; return 0; }                              /* :226 .ok()? */
     memcpy(mask, f->fs.mask, 32);
     return 1;

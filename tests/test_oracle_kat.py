@@ -140,6 +140,45 @@ def test_tail_quirk_mode_documents_reference_bug(oracle):
     assert list(out) == [0x12345678] * 7 + [0]
 
 
+def test_tail_quirk_sees_the_vector_slice_not_the_section(oracle):
+    """The slice the reference's octet decoder measures against 34 bytes runs to the end of the VECTOR
+    (section.rs:548, :636, :706 keep sect_bytes = rest of the slice; vector.rs:443), so only octets
+    within the last 33 bytes of a vector are hit, not the last octets of every section."""
+    vals = np.full(512, 0x12345678, dtype=np.uint32)      # two NibblePack sections of 8-nibble octets
+    vals[255] = 0                                         # last octet of section 0: 30 bytes
+    vals[511] = 0                                         # last octet of section 1 (end of the vector): 30 bytes
+    buf = oracle.encode_all(oracle.U32, vals)
+    good = oracle.decode_to_vec(oracle.U32, buf)
+    assert list(good) == list(vals)
+    with oracle.ref_tail_quirk():
+        bad = oracle.decode_to_vec(oracle.U32, buf)
+    assert list(bad[:504]) == list(vals[:504])            # section 0 whole, section 1 up to its last octet
+    assert list(bad[504:]) == [0] * 8
+    # the same bytes followed by 4 more bytes of slice (a reader handed a longer buffer): 34 bytes are left, no difference
+    with oracle.ref_tail_quirk():
+        assert list(oracle.decode_to_vec(oracle.U32, buf + b"\0" * 4)[:512]) == list(vals)
+
+
+def test_tail_quirk_census_of_the_bench_configurations(oracle):
+    """Where a real `cargo` run of the reference would differ from the wire format's bitstream rule, per
+    benchmark configuration.  2048-element f32 XOR vectors end exactly on a section, so their last octet
+    is usually within 33 bytes of the end of the slice: 1638 of the first 2048 vectors of the sinusoid
+    data set (80 %) and 11466 decoded elements differ.  10000-element vectors end in 240 padded zeros
+    (30 one-byte octets) and the SplitMix data set has 3-nibble XOR octets: no difference."""
+    from compressed_vec_amd import synth
+    v, eo = synth.batch_values("f32_xor", 2048, 2048)
+    blob, bo = oracle.batch_encode(oracle.F32, v, eo)
+    assert oracle.tail_quirk_census(oracle.F32, blob, bo, pred=3.0) == (1638, 11466, 0)
+    assert oracle.tail_quirk_census(oracle.F32, blob, bo, pred=float(v[1]))[2] == -1
+    v, eo = synth.splitmix_f32(512, 2048)
+    blob, bo = oracle.batch_encode(oracle.F32, v, eo)
+    assert oracle.tail_quirk_census(oracle.F32, blob, bo) == (0, 0, None)
+    for kind, et in [("u32_dense", oracle.U32), ("f32_xor", oracle.F32), ("u64_delta", oracle.U64)]:
+        v, eo = synth.batch_values(kind, 16, synth.VECTOR_LENGTH)
+        blob, bo = oracle.batch_encode(et, v, eo)
+        assert oracle.tail_quirk_census(et, blob, bo) == (0, 0, None)
+
+
 # ---- section.rs ---------------------------------------------------------------------------
 
 def test_fixedsect_iterator_null_then_np(oracle):
