@@ -11,6 +11,7 @@ U64, U32, F32 = 0x10, 0x11, 0x12
 PRED_EQ, PRED_ONEOF = 0, 1
 MAX_PRED_VALUES = 16
 RESULT_WORDS = 4
+STATIC_SCRATCH_BYTES = 2 * 1024 * 1024
 
 OK = 0
 NOT_ENOUGH_SPACE, INPUT_TOO_SHORT, BAD_OFFSET, INVALID_SECTION_TYPE, INVALID_FORMAT, INVALID_NUM_ROWS, \
@@ -73,6 +74,8 @@ SIGNATURES = {
                                       C.c_void_p]),
     "cvec_filter_count_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_filter_count_static_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvec_filter_count_gated_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                                 C.c_void_p]),

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "cvec_device.hpp"
@@ -61,6 +62,15 @@ hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_
 using namespace cvec;
 
 static thread_local char g_hip_err[256] = "";
+
+// Scratch of cvec_filter_count_static_dev: the workspace that the other read entry points take as an
+// argument, as a file-scope device array.  Every GPU the library runs on holds its own copy until the
+// process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the address
+// that kernels, memsets and copies use is looked up once per device (with that device current) and
+// kept in g_static_scratch[device].
+static __device__ __align__(256) unsigned char scratch[CVEC_STATIC_SCRATCH_BYTES];
+constexpr int MAX_STATIC_DEVICES = 64;
+static std::atomic<void *> g_static_scratch[MAX_STATIC_DEVICES];
 
 static cvec_status hip_fail(hipError_t e, const char *what) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
@@ -331,6 +341,21 @@ const char *cvec_status_name(cvec_status s) {
     }
 }
 
+// The current device's copy of `scratch` (looked up on the first use on that device).
+static cvec_status static_scratch(void **out) {
+    int d = -1;
+    HIP_TRY(hipGetDevice(&d));
+    if (d < 0 || d >= MAX_STATIC_DEVICES) return CVEC_ERR_BAD_ARGUMENT;
+    void *p = g_static_scratch[d].load(std::memory_order_acquire);
+    if (!p) {
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return hip_fail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
+        g_static_scratch[d].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return CVEC_OK;
+}
+
 cvec_status cvec_init(int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -338,7 +363,8 @@ cvec_status cvec_init(int device) {
     if (device < 0 || device >= count) return CVEC_ERR_BAD_ARGUMENT;
     HIP_TRY(hipSetDevice(device));
     (void)hipFree(nullptr);
-    return CVEC_OK;
+    void *p = nullptr;
+    return static_scratch(&p); // this device's address of the static scratch, so that no later call has to look it up
 }
 
 cvec_status cvec_timing_begin(int32_t max_records) {
@@ -389,13 +415,13 @@ cvec_status cvec_sec_base_dev(const uint8_t *d_bytes, const uint64_t *d_byte_off
                               uint64_t *d_sec_base, uint64_t *h_n_sections, void *stream) {
     if (!d_byte_off || !d_sec_base || (n_vectors && !d_bytes)) return CVEC_ERR_BAD_ARGUMENT;
     hipStream_t s = (hipStream_t)stream;
-    uint64_t *scratch = nullptr;
-    HIP_TRY(hipMalloc((void **)&scratch, scan_scratch_words(n_vectors) * 8));
-    hipError_t e = launch_sec_base(d_bytes, d_byte_off, n_vectors, d_sec_base, scratch, s);
+    uint64_t *scan_tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&scan_tmp, scan_scratch_words(n_vectors) * 8));
+    hipError_t e = launch_sec_base(d_bytes, d_byte_off, n_vectors, d_sec_base, scan_tmp, s);
     uint64_t total = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&total, d_sec_base + n_vectors, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(scratch);
+    (void)hipFree(scan_tmp);
     if (e != hipSuccess) return hip_fail(e, "cvec_sec_base_dev");
     if (h_n_sections) *h_n_sections = total;
     return CVEC_OK;
@@ -452,6 +478,27 @@ cvec_status cvec_filter_count_indexed_dev(const cvec_dbatch_view *batch, const c
                                           uint8_t *d_masks, void *d_workspace, size_t workspace_bytes, void *stream) {
     return filter_count_phase(READ_INDEXED, batch, pred, d_gate, d_result, d_per_vector, d_status, d_masks,
                               d_workspace, workspace_bytes, stream);
+}
+
+cvec_status cvec_filter_count_static_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
+                                         uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *stream) {
+    if (!batch) return CVEC_ERR_BAD_ARGUMENT;
+    const size_t need = cvec_workspace_bytes(batch->n_vectors, batch->n_sections);
+    if (need > (size_t)CVEC_STATIC_SCRATCH_BYTES) {
+        snprintf(g_hip_err, sizeof(g_hip_err),
+                 "cvec_filter_count_static_dev: a batch of %llu vectors / %llu sections needs %zu bytes of scratch, the "
+                 "static scratch holds %d (use cvec_filter_count_dev with a workspace)",
+                 (unsigned long long)batch->n_vectors, (unsigned long long)batch->n_sections, need,
+                 (int)CVEC_STATIC_SCRATCH_BYTES);
+        return CVEC_ERR_WORKSPACE;
+    }
+    void *ws = nullptr;
+    cvec_status st = static_scratch(&ws);
+    if (st) return st;
+    // Every slot of the scratch that the kernels read is written earlier in the same call (descriptors,
+    // per-section results, per-vector header statuses, the index tag), so nothing has to be cleared.
+    return filter_count_phase(READ_ALL, batch, pred, nullptr, d_result, d_per_vector, d_status, d_masks, ws,
+                              CVEC_STATIC_SCRATCH_BYTES, stream);
 }
 
 static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, const cvec_pred *pred,

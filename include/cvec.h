@@ -138,6 +138,19 @@ cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred
                                   uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
                                   void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* cvec_filter_count_dev without a workspace argument and without any allocation: the scratch is a
+ * static device array inside the library (CVEC_STATIC_SCRATCH_BYTES per GPU, held until the process
+ * ends).  No counterpart in the reference; it exists for callers that cannot allocate or size device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The
+ * call makes no hipMalloc / hipFree and calls no allocating routine.  A batch whose
+ * cvec_workspace_bytes(n_vectors, n_sections) exceeds CVEC_STATIC_SCRATCH_BYTES (about 170 000
+ * sections) is rejected with CVEC_ERR_WORKSPACE and a message in cvec_last_hip_error().  All calls on
+ * one GPU share that GPU's scratch: calls that overlap in time on one GPU (two streams, two threads)
+ * race and must be serialised by the caller.  Results are identical to cvec_filter_count_dev's. */
+#define CVEC_STATIC_SCRATCH_BYTES (2 * 1024 * 1024)
+cvec_status cvec_filter_count_static_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
+                                         uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *stream);
+
 /* The same, behind a gate: d_gate (nullable, 16-byte aligned) holds n_sections * 32 bytes, the masks
  * an earlier filter pass wrote for a batch with the same sec_base (e.g. the previous column of a
  * MultiVectorFilter).  A section whose gate mask is empty is parsed but not decoded, like the
