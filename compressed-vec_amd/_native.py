@@ -16,12 +16,12 @@ STATIC_SCRATCH_BYTES = 2 * 1024 * 1024
 OK = 0
 NOT_ENOUGH_SPACE, INPUT_TOO_SHORT, BAD_OFFSET, INVALID_SECTION_TYPE, INVALID_FORMAT, INVALID_NUM_ROWS, \
     WRONG_VECTOR_TYPE, SCROLL_ERR = range(1, 9)
-ERR_SECTION_COUNT, ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_WORKSPACE = 100, 101, 102, 103, 104
+ERR_SECTION_COUNT, ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_WORKSPACE, ERR_CAPACITY = 100, 101, 102, 103, 104, 105
 
 _NAMES = {0: "Ok", 1: "NotEnoughSpace", 2: "InputTooShort", 3: "BadOffset", 4: "InvalidSectionType",
           5: "InvalidFormat", 6: "InvalidNumRows", 7: "WrongVectorType", 8: "ScrollErr",
           100: "SectionCountMismatch", 101: "BadArgument", 102: "HipError", 103: "NoDevice",
-          104: "WorkspaceTooSmall"}
+          104: "WorkspaceTooSmall", 105: "OutputTooSmall"}
 
 
 class CodingError(Exception):
@@ -120,6 +120,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cvec_encode_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cvec_debug_fail_chunk": (C.c_int32, [C.c_int64]),
 }
 
 _lib = None

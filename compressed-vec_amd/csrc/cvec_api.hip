@@ -188,10 +188,42 @@ template <class S> struct SlotCache {
 
 // filter + count (decode == false) or decode through the sink chain (decode == true) of a batch in
 // host memory, chunk by chunk.  `r` receives the summed result block.
+// Ends a pipelined call that failed half way: earlier chunks may still be copying into the caller's
+// buffers and into the slots' staging on any of the three streams, and the next call reuses the slots
+// without looking at their events.  Waits for all three streams; keeps the first error.
+template <class Cache> cvec_status drain_pipeline(Cache *cache, cvec_status st) {
+    if (st != CVEC_OK && cache) {
+        for (hipStream_t s : {cache->s_in.s, cache->s_run.s, cache->s_out.s})
+            if (s) (void)hipStreamSynchronize(s);
+    }
+    return st;
+}
+
+// Test hook (tests/test_gpu_parity.py): the chunk index at which the next pipelined call of this thread
+// fails artificially after its copies have been queued, -1 = never.  Set through cvec_debug_fail_chunk.
+thread_local int64_t g_fail_chunk = -1;
+
+cvec_status read_pipeline_body(SlotCache<ReadSlot> *cache, bool decode, int32_t etype, const uint8_t *h_bytes,
+                               const uint64_t *h_byte_off, uint64_t n, const cvec_pred *pred,
+                               const cvec_sink_chain *chain, uint64_t r[CVEC_RESULT_WORDS], uint64_t *h_per_vector,
+                               int32_t *h_status, void *h_out, uint64_t out_cap_elems, uint64_t *h_out_off);
+
 cvec_status read_pipeline(bool decode, int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off, uint64_t n,
                           const cvec_pred *pred, const cvec_sink_chain *chain, uint64_t r[CVEC_RESULT_WORDS],
                           uint64_t *h_per_vector, int32_t *h_status, void *h_out, uint64_t out_cap_elems,
                           uint64_t *h_out_off) {
+    // The slots (device buffers, pinned offsets, streams) are kept per host thread and device and only
+    // grow: allocating them costs as much as moving tens of MiB over PCIe.  They are never freed (a
+    // destructor at thread or process exit could run after the HIP runtime has shut down).
+    static thread_local SlotCache<ReadSlot> *cache = new SlotCache<ReadSlot>();
+    return drain_pipeline(cache, read_pipeline_body(cache, decode, etype, h_bytes, h_byte_off, n, pred, chain, r,
+                                                    h_per_vector, h_status, h_out, out_cap_elems, h_out_off));
+}
+
+cvec_status read_pipeline_body(SlotCache<ReadSlot> *cache, bool decode, int32_t etype, const uint8_t *h_bytes,
+                               const uint64_t *h_byte_off, uint64_t n, const cvec_pred *pred,
+                               const cvec_sink_chain *chain, uint64_t r[CVEC_RESULT_WORDS], uint64_t *h_per_vector,
+                               int32_t *h_status, void *h_out, uint64_t out_cap_elems, uint64_t *h_out_off) {
     if (!etype_ok(etype) || !h_byte_off || (n && !h_bytes)) return CVEC_ERR_BAD_ARGUMENT;
     for (uint64_t v = 0; v < n; v++)
         if (h_byte_off[v + 1] < h_byte_off[v]) return CVEC_ERR_BAD_ARGUMENT;
@@ -211,7 +243,7 @@ cvec_status read_pipeline(bool decode, int32_t etype, const uint8_t *h_bytes, co
         if (h_out_off)
             for (uint64_t v = 0; v <= n; v++) h_out_off[v] = sec_base[v] * FIXED_LEN;
         const uint64_t n_out = sec_base[n] * FIXED_LEN;
-        if (n_out > out_cap_elems || (n_out && !h_out)) return CVEC_NOT_ENOUGH_SPACE;
+        if (n_out > out_cap_elems || (n_out && !h_out)) return CVEC_ERR_CAPACITY;
     }
     const std::vector<uint64_t> first = plan_chunks(n, pipe_chunk_bytes(), [&](uint64_t v) {
         return h_byte_off[v + 1] - h_byte_off[v] + 16 + (decode ? (sec_base[v + 1] - sec_base[v]) * FIXED_LEN * w : 0);
@@ -224,10 +256,6 @@ cvec_status read_pipeline(bool decode, int32_t etype, const uint8_t *h_bytes, co
         max_sec = std::max(max_sec, sec_base[first[c + 1]] - sec_base[first[c]]);
     }
     const size_t nslots = std::min<size_t>(PIPE_SLOTS, std::max<size_t>(nchunks, 1));
-    // The slots (device buffers, pinned offsets, streams) are kept per host thread and device and only
-    // grow: allocating them costs as much as moving tens of MiB over PCIe.  They are never freed (a
-    // destructor at thread or process exit could run after the HIP runtime has shut down).
-    static thread_local SlotCache<ReadSlot> *cache = new SlotCache<ReadSlot>();
     ReadSlot *slots = cache->get();
     if (!slots) return hip_fail(hipGetLastError(), "pipeline streams");
     hipStream_t s_in = cache->s_in.s, s_run = cache->s_run.s, s_out = cache->s_out.s;
@@ -294,6 +322,7 @@ cvec_status read_pipeline(bool decode, int32_t etype, const uint8_t *h_bytes, co
                                        h_status ? sl.stt.as<int32_t>() : nullptr, nullptr, sl.ws.p, wsb, s_run);
         }
         if (st) return st;
+        if (g_fail_chunk == (int64_t)c) { g_fail_chunk = -1; return CVEC_ERR_HIP; } // test hook: fail with work in flight
         HIP_TRY(hipEventRecord(sl.ev_run.e, s_run));
         HIP_TRY(hipStreamWaitEvent(s_out, sl.ev_run.e, 0));
         HIP_TRY(hipMemcpyAsync(sl.hres.p, sl.res.p, CVEC_RESULT_WORDS * 8, hipMemcpyDeviceToHost, s_out));
@@ -337,6 +366,7 @@ const char *cvec_status_name(cvec_status s) {
     case CVEC_ERR_HIP: return "HipError";
     case CVEC_ERR_NO_DEVICE: return "NoDevice";
     case CVEC_ERR_WORKSPACE: return "WorkspaceTooSmall";
+    case CVEC_ERR_CAPACITY: return "OutputTooSmall";
     default: return "Unknown";
     }
 }
@@ -657,7 +687,7 @@ cvec_status cvec_stream_pack_dev(int32_t kind, const uint64_t *d_values, const u
         return CVEC_ERR_BAD_ARGUMENT;
     if (n_values_total && !d_values) return CVEC_ERR_BAD_ARGUMENT;
     if (((uintptr_t)d_bytes & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
-    if (bytes_cap < cvec_stream_max_packed_bytes(kind, n_streams, n_values_total)) return CVEC_NOT_ENOUGH_SPACE;
+    if (bytes_cap < cvec_stream_max_packed_bytes(kind, n_streams, n_values_total)) return CVEC_ERR_CAPACITY;
     if (stream_pack_workspace_bytes(n_streams, n_values_total) > workspace_bytes) return CVEC_ERR_WORKSPACE;
     hipError_t e = launch_stream_pack(kind, d_values, d_elem_off, n_streams, n_values_total, d_bytes, d_byte_off,
                                       d_status, d_result, d_workspace, (hipStream_t)stream);
@@ -699,7 +729,7 @@ cvec_status cvec_hist_delta_diff_dev(const uint8_t *d_bytes, const uint64_t *d_b
         return CVEC_ERR_BAD_ARGUMENT;
     if (num_buckets > 0xffff) return CVEC_ERR_BAD_ARGUMENT; // BinHistogramHeader.num_buckets is a u16 (src/histogram.rs:21)
     if ((((uintptr_t)d_bytes) & 15) != 0 || (((uintptr_t)d_out) & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
-    if (out_cap < cvec_hist_max_packed_bytes(n_hist, num_buckets)) return CVEC_NOT_ENOUGH_SPACE;
+    if (out_cap < cvec_hist_max_packed_bytes(n_hist, num_buckets)) return CVEC_ERR_CAPACITY;
     if (workspace_bytes < hist_workspace_bytes(n_hist, num_buckets)) return CVEC_ERR_WORKSPACE;
     hipError_t e = launch_hist_delta_diff(d_bytes, d_byte_off, n_bytes, d_series_off, n_series, n_hist, num_buckets, d_out,
                                           d_out_off, d_dropped, d_status, d_result, d_workspace, (hipStream_t)stream);
@@ -727,7 +757,7 @@ cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t 
         return CVEC_ERR_BAD_ARGUMENT;
     if (n_elements_total && !d_values) return CVEC_ERR_BAD_ARGUMENT;
     if (((uintptr_t)d_bytes & 15) != 0) return CVEC_ERR_BAD_ARGUMENT;
-    if (bytes_cap < cvec_max_encoded_bytes(etype, n_vectors, n_elements_total)) return CVEC_NOT_ENOUGH_SPACE;
+    if (bytes_cap < cvec_max_encoded_bytes(etype, n_vectors, n_elements_total)) return CVEC_ERR_CAPACITY;
     if (workspace_bytes < encode_workspace_bytes(n_vectors, n_elements_total)) return CVEC_ERR_WORKSPACE;
     hipError_t e = launch_encode(etype, d_values, d_elem_off, n_vectors, n_elements_total, d_bytes, bytes_cap,
                                  d_byte_off, d_sec_base, d_result, d_workspace, workspace_bytes, (hipStream_t)stream);
@@ -765,8 +795,25 @@ cvec_status cvec_decode_batch(int32_t etype, const uint8_t *h_bytes, const uint6
     return summary_status(r);
 }
 
+static cvec_status encode_pipeline_body(SlotCache<EncSlot> *cache, int32_t etype, const void *h_values,
+                                        const uint64_t *h_elem_off, uint64_t n_vectors, uint8_t *h_bytes, size_t bytes_cap,
+                                        uint64_t *h_byte_off, uint64_t *h_total_bytes);
+
 cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_t *h_elem_off, uint64_t n_vectors,
                               uint8_t *h_bytes, size_t bytes_cap, uint64_t *h_byte_off, uint64_t *h_total_bytes) {
+    static thread_local SlotCache<EncSlot> *cache = new SlotCache<EncSlot>();
+    return drain_pipeline(cache, encode_pipeline_body(cache, etype, h_values, h_elem_off, n_vectors, h_bytes, bytes_cap,
+                                                      h_byte_off, h_total_bytes));
+}
+
+cvec_status cvec_debug_fail_chunk(int64_t chunk) {
+    g_fail_chunk = chunk;
+    return CVEC_OK;
+}
+
+static cvec_status encode_pipeline_body(SlotCache<EncSlot> *cache, int32_t etype, const void *h_values,
+                                        const uint64_t *h_elem_off, uint64_t n_vectors, uint8_t *h_bytes, size_t bytes_cap,
+                                        uint64_t *h_byte_off, uint64_t *h_total_bytes) {
     if (!etype_ok(etype) || !h_elem_off || !h_byte_off || !h_bytes) return CVEC_ERR_BAD_ARGUMENT;
     for (uint64_t v = 0; v < n_vectors; v++) {
         if (h_elem_off[v + 1] < h_elem_off[v]) return CVEC_ERR_BAD_ARGUMENT;
@@ -786,7 +833,6 @@ cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_
         max_el = std::max(max_el, h_elem_off[first[c + 1]] - h_elem_off[first[c]]);
     }
     const size_t nslots = std::min<size_t>(PIPE_SLOTS, std::max<size_t>(nchunks, 1));
-    static thread_local SlotCache<EncSlot> *cache = new SlotCache<EncSlot>();
     EncSlot *slots = cache->get();
     if (!slots) return hip_fail(hipGetLastError(), "pipeline streams");
     hipStream_t s_in = cache->s_in.s, s_run = cache->s_run.s, s_out = cache->s_out.s;
@@ -863,6 +909,7 @@ cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_
         st = cvec_encode_dev(etype, sl.vals.p, sl.eoff.as<uint64_t>(), nv, n_el, sl.bytes.as<uint8_t>(), cap,
                              sl.boff.as<uint64_t>(), sl.sbase.as<uint64_t>(), sl.res.as<uint64_t>(), sl.ws.p, wsb, s_run);
         if (st) return st;
+        if (g_fail_chunk == (int64_t)c) { g_fail_chunk = -1; return CVEC_ERR_HIP; } // test hook: fail with work in flight
         HIP_TRY(hipEventRecord(sl.ev_run.e, s_run));
         HIP_TRY(hipStreamWaitEvent(s_out, sl.ev_run.e, 0));
         HIP_TRY(hipMemcpyAsync(sl.hres.p, sl.res.p, CVEC_RESULT_WORDS * 8, hipMemcpyDeviceToHost, s_out));
@@ -880,7 +927,7 @@ cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_
     }
     HIP_TRY(hipStreamSynchronize(s_out));
     if (h_total_bytes) *h_total_bytes = total;
-    if (overflow) return CVEC_NOT_ENOUGH_SPACE;
+    if (overflow) return CVEC_ERR_CAPACITY;
     h_byte_off[n_vectors] = total;
     return CVEC_OK;
 }

@@ -691,7 +691,12 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
     typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
     u32x4 R[PIECES];
     auto issue_loads = [&](const ChunkPlan &c) {
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)(sa._pad == 5 ? 0u : c.nch * 16u), 0x00020000);
+#ifdef CVEC_PROBES
+        const uint32_t span_bytes = sa._pad == 5 ? 0u : c.nch * 16u; // probe build: the loop without HBM traffic
+#else
+        const uint32_t span_bytes = c.nch * 16u;
+#endif
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)span_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < PIECES; i++)
             R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 2 /* nt: read once */);
@@ -785,7 +790,11 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
                 mk_lo = mk_hi = all ? ~0u : 0u;
                 mk_pending = cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
             }
-        } else if (cur.n != 0 && sa._pad != 1) {
+#ifdef CVEC_PROBES
+        } else if (cur.n != 0 && sa._pad != 1) { // probe build: 1 = stage the bytes but skip the octet loop
+#else
+        } else if (cur.n != 0) {
+#endif
             const bool odd = process_chunk<ETYPE, MODE, NPRED, false, PIECES>(data, lds_base, cur.kind, cur.rel, cur.len,
                                                                       sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
                                                                       mk_lo, mk_hi, out_);
@@ -944,9 +953,16 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         // range of section slots (a multiple of TILE).  Count-only passes over a batch whose average
         // section is small enough for 16 of them to fit a 12 KiB region run 3 workgroups per CU on such
         // regions (n_bytes == 0: size unknown, the large shape).
+        // The product build takes no run-time switches.  A probe build (make probes: -DCVEC_PROBES, a separate
+        // library for the timing tools) reads experiment settings from the environment.
+#ifdef CVEC_PROBES
         static const int rounds = [] { const char *e = getenv("CVEC_WG_ROUNDS"); return e ? atoi(e) : 1; }();
         static const int wgcu_env = [] { const char *e = getenv("CVEC_WG_PER_CU"); return e ? atoi(e) : 0; }();
         static const int shape_env = [] { const char *e = getenv("CVEC_REGION_SHAPE"); return e ? atoi(e) : 0; }(); // 1 = always large, 2 = small where possible
+        static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
+#else
+        constexpr int rounds = 1, wgcu_env = 0, shape_env = 0, ablate = 0;
+#endif
         const bool count_only = mode != MODE_DECODE && d_masks == nullptr;
         bool small = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL);
         if (shape_env == 1) small = false;
@@ -958,9 +974,8 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (per < 2 * TILE) per = 2 * TILE;
         const uint64_t nwaves = (ns + per - 1) / per;
         const uint32_t nwg = (uint32_t)((nwaves + SEC_WAVES - 1) / SEC_WAVES);
-        static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
         SinkArgs sa2 = sa;
-        sa2._pad = (uint32_t)ablate; // timing experiments only: 1 = stage the bytes but skip the octet loop, 5 = loop without HBM traffic
+        sa2._pad = (uint32_t)ablate; // always 0 in the product build
         // the predicate list padded to its bucket with copies of the first value
         PredArgs pb = pa;
         uint32_t bucket = 1;

@@ -35,7 +35,7 @@ def encode_host(etype, values, elem_off, out=None):
     cap = L.cvec_max_encoded_bytes(etype, n, int(eo[-1] - eo[0]))
     blob = out if out is not None else np.empty(cap, dtype=np.uint8)
     if blob.size < cap:
-        raise N.CodingError(N.NOT_ENOUGH_SPACE)
+        raise N.CodingError(N.ERR_CAPACITY)
     bo = np.zeros(n + 1, dtype=np.uint64)
     total = C.c_uint64(0)
     N.check(L.cvec_encode_batch(etype, _p(vals), _p(eo), n, _p(blob), blob.size, _p(bo), C.byref(total)))
@@ -52,7 +52,9 @@ def filter_count_host(batch, pred, per_vector=False, return_status=False):
     st = np.zeros(n, dtype=np.int32) if return_status else None
     rc = L.cvec_filter_count_batch(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(p), C.byref(total),
                                    _p(per) if per is not None else None, _p(st) if st is not None else None)
-    if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT):
+    # 1..8 and ERR_SECTION_COUNT are "the largest per-vector status" (the statuses say which vectors);
+    # anything above is a failure of the call as a whole
+    if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT and st.any()):
         N.check(rc)
     out = [total.value]
     if per_vector:
@@ -85,6 +87,6 @@ def decode_host(batch, add_const=None, return_status=False, out=None):
     chain = make_chain(batch.etype, add_const)
     rc = L.cvec_decode_batch(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(chain), _p(vals), vals.size,
                              _p(out_off), _p(st) if st is not None else None)
-    if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT):
+    if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT and st.any()):
         N.check(rc)
     return (vals, out_off, st) if return_status else (vals, out_off)

@@ -16,7 +16,10 @@
  * Conventions
  *  - Plain pointers and sizes only.  `d_` parameters are device pointers, `h_` host pointers.
  *  - Every function returns a cvec_status: 0 = OK, 1..8 = the reference's CodingError discriminant
- *    (src/error.rs:2-11), >= 100 = errors of this library (HIP failures, bad arguments).
+ *    (src/error.rs:2-11), >= 100 = errors of this library (HIP failures, bad arguments).  A call-level
+ *    failure (bad argument, workspace or output capacity, HIP error) is always >= 101 and means that no
+ *    result was produced; the *_batch entry points return 1..8 or CVEC_ERR_SECTION_COUNT only as "the
+ *    largest per-vector status", with every vector's own status in h_status.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  `_dev` functions only
  *    enqueue work; results are valid after the stream is synchronised.
  *  - No exceptions or panics cross this boundary.
@@ -49,7 +52,9 @@ enum {
     CVEC_ERR_BAD_ARGUMENT = 101,
     CVEC_ERR_HIP = 102,           /* a HIP runtime call failed; see cvec_last_hip_error() */
     CVEC_ERR_NO_DEVICE = 103,
-    CVEC_ERR_WORKSPACE = 104      /* workspace too small */
+    CVEC_ERR_WORKSPACE = 104,     /* workspace too small */
+    CVEC_ERR_CAPACITY = 105       /* a caller-provided output buffer is too small for the whole call; nothing was produced
+                                     (never a per-vector status: those are 1..8 and CVEC_ERR_SECTION_COUNT) */
 };
 
 /* Element type = the vector header's minor-type byte (src/vector.rs:94-96). */
@@ -235,7 +240,7 @@ cvec_status cvec_match_positions_dev(const cvec_mask_column *col, uint64_t n_vec
  * d_values[elem_off[v] .. elem_off[v+1]).  Replaces src/vector.rs:238-246 (append → encode_section
  * → finish) with AutoEncoder (src/section.rs:819-846) for u32/u64 and XorNPMedFixedSect
  * (src/section.rs:716-754) for f32.  Writes the blob to d_bytes (capacity bytes_cap, must be
- * >= cvec_max_encoded_bytes), d_byte_off[n+1] and d_sec_base[n+1]; d_result[0] = blob size. */
+ * >= cvec_max_encoded_bytes, else CVEC_ERR_CAPACITY), d_byte_off[n+1] and d_sec_base[n+1]; d_result[0] = blob size. */
 size_t cvec_max_encoded_bytes(int32_t etype, uint64_t n_vectors, uint64_t n_elements_total);
 size_t cvec_encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
 cvec_status cvec_encode_dev(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
@@ -320,6 +325,12 @@ cvec_status cvec_decode_batch(int32_t etype, const uint8_t *h_bytes, const uint6
 cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_t *h_elem_off, uint64_t n_vectors,
                               uint8_t *h_bytes, size_t bytes_cap, uint64_t *h_byte_off /* n+1 */,
                               uint64_t *h_total_bytes);
+
+/* Test hook, no counterpart in the reference: makes the next *_batch call of the calling thread fail
+ * with CVEC_ERR_HIP at chunk `chunk` (0-based) after that chunk's copies and kernels have been queued,
+ * to exercise the error exit of the pipeline (which must wait for everything in flight before it
+ * returns).  -1 disarms.  The hook disarms itself when it fires. */
+cvec_status cvec_debug_fail_chunk(int64_t chunk);
 
 #ifdef __cplusplus
 }

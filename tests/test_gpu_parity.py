@@ -896,3 +896,41 @@ def test_full_size_properties_cfg5_shape(cv):
     t, per = dev.filter_count(float(distinct[3]), per_vector=True)
     assert int(per.sum()) == t
     assert dev.filter_count([float(x) for x in distinct[:8]]) == sum(dev.filter_count(float(x)) for x in distinct[:8])
+
+
+def test_pipeline_error_exit_drains_and_the_next_call_is_clean(cv, oracle, monkeypatch):
+    """A *_batch call that fails at a chunk in the middle (injected after that chunk's copies and kernels
+    were queued) must return the error only when nothing of it is in flight any more: the next call on
+    the same thread reuses the slots at once and has to produce the oracle's results; a too small output
+    buffer is a call-level error (>= 101), never a per-vector status."""
+    from compressed_vec_amd import _native as N
+    monkeypatch.setenv("CVEC_PIPE_CHUNK_BYTES", "20000")
+    rng = np.random.default_rng(99)
+    vals, eo = _random_vectors(rng, "u32", 200, max_len=2500)
+    blob, bo = oracle.batch_encode(ET["u32"], vals, eo)
+    host = cv.EncodedBatch("u32", cv.hostpath.pin(blob), bo)
+    for fail_at in (0, 3, 7):
+        for op in ("decode", "filter", "encode"):
+            assert cv.lib().cvec_debug_fail_chunk(fail_at) == 0
+            with pytest.raises(cv.CodingError) as e:
+                if op == "decode":
+                    cv.decode_host(host)
+                elif op == "filter":
+                    cv.filter_count_host(host, 5)
+                else:
+                    cv.encode_host("u32", vals, eo)
+            assert e.value.code == N.ERR_HIP
+            # straight into the next call, same slots
+            dec, out_off = cv.decode_host(host)
+            want, _, rc = oracle.batch_decode(ET["u32"], blob, bo, out_off)
+            assert rc == 0 and np.array_equal(dec, want)
+            total, per = cv.filter_count_host(host, 5, per_vector=True)
+            wtotal, wper, _, rc = oracle.batch_filter_count(ET["u32"], blob, bo, 5)
+            assert rc == 0 and total == wtotal and np.array_equal(per, wper)
+            got = cv.encode_host("u32", vals, eo)
+            assert np.array_equal(got.blob, blob) and np.array_equal(got.byte_off, bo)
+    assert cv.lib().cvec_debug_fail_chunk(-1) == 0
+    small = np.zeros(256, dtype=np.uint32)
+    with pytest.raises(cv.CodingError) as e:
+        cv.decode_host(host, out=small, return_status=True)
+    assert e.value.code == N.ERR_CAPACITY
