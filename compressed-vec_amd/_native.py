@@ -12,6 +12,7 @@ PRED_EQ, PRED_ONEOF = 0, 1
 MAX_PRED_VALUES = 16
 RESULT_WORDS = 4
 STATIC_SCRATCH_BYTES = 2 * 1024 * 1024
+PATH_AUTO, PATH_SLOTS, PATH_VSTREAM = 0, 1, 2
 
 OK = 0
 NOT_ENOUGH_SPACE, INPUT_TOO_SHORT, BAD_OFFSET, INVALID_SECTION_TYPE, INVALID_FORMAT, INVALID_NUM_ROWS, \
@@ -66,6 +67,7 @@ SIGNATURES = {
     "cvec_init": (C.c_int32, [C.c_int]),
     "cvec_last_hip_error": (C.c_char_p, []),
     "cvec_status_name": (C.c_char_p, [C.c_int32]),
+    "cvec_set_read_path": (C.c_int32, [C.c_int32]),
     "cvec_timing_begin": (C.c_int32, [C.c_int32]),
     "cvec_timing_end": (C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(C.c_int32)]),
@@ -87,7 +89,8 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_decode_indexed_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(SinkChain), C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "cvec_valid_sections_dev": (C.c_int32, [C.POINTER(DBatchView), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "cvec_valid_sections_dev": (C.c_int32, [C.POINTER(DBatchView), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "cvec_multi_workspace_bytes": (C.c_size_t, [C.c_uint64]),
     "cvec_multi_filter_count_dev": (C.c_int32, [C.POINTER(MaskColumn), C.c_uint32, C.c_uint64, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

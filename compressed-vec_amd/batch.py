@@ -209,13 +209,16 @@ class DeviceBatch:
             self._result = torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device=self.device)
         return self._result
 
-    def section_results(self):
-        """Per-section result words of the last operation (low 16 bits: count, high 16: status), read
-        back from the workspace; for inspecting where a malformed vector stopped."""
+    def valid_sections(self):
+        """After a filter or decode pass: (leading sections of every vector that produced a mask / data,
+        flags of the vectors whose iteration ended at a header that does not parse), as numpy arrays."""
         ws = self.workspace()
-        off = ((self.n_sections + 1) * 8 + 255) // 256 * 256
-        raw = ws[off:off + 4 * self.n_sections].cpu().numpy()
-        return raw.view(np.uint32)
+        valid = torch.empty(max(self.n_vectors, 1), dtype=torch.int32, device=self.device)
+        pf = torch.zeros(max(self.n_vectors, 1), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().cvec_valid_sections_dev(C.byref(self.view), _ptr(ws), ws.numel(), _ptr(valid), _ptr(pf),
+                                                    _stream_ptr()))
+        return valid.cpu().numpy()[:self.n_vectors].view(np.uint32), pf.cpu().numpy()[:self.n_vectors].astype(bool)
 
     # -- operations -------------------------------------------------------------------------------------
     def build_index(self):
@@ -238,6 +241,8 @@ class DeviceBatch:
         p = pred if isinstance(pred, N.Pred) else make_pred(self.etype, pred)
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
+        if self._keep_index and not self._index_valid:
+            self.build_index()                  # an unindexed pass used the workspace since: walk the headers again
         with torch.cuda.device(self.device):
             if self._keep_index and self._index_valid:
                 N.check(N.lib().cvec_filter_count_indexed_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
@@ -247,7 +252,7 @@ class DeviceBatch:
                 N.check(N.lib().cvec_filter_count_gated_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
                                                             _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
                                                             ws.numel(), _stream_ptr()))
-                self._index_valid = gate is None
+                self._index_valid = False       # only cvec_index_dev and the indexed calls keep an index
         return res
 
     def filter_count(self, pred, per_vector=False, return_status=False, return_masks=False):
@@ -280,7 +285,7 @@ class DeviceBatch:
         valid = torch.empty(max(self.n_vectors, 1), dtype=torch.int32, device=self.device)
         ws = self.workspace()
         with torch.cuda.device(self.device):
-            N.check(N.lib().cvec_valid_sections_dev(C.byref(self.view), _ptr(ws), ws.numel(), _ptr(valid),
+            N.check(N.lib().cvec_valid_sections_dev(C.byref(self.view), _ptr(ws), ws.numel(), _ptr(valid), None,
                                                     _stream_ptr()))
         return FilteredColumn(self, masks, valid, res.clone())
 
@@ -291,10 +296,11 @@ class DeviceBatch:
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
         with torch.cuda.device(self.device):
-            fn = N.lib().cvec_decode_indexed_dev if self._keep_index and self._index_valid else N.lib().cvec_decode_dev
+            indexed = self._keep_index and self._index_valid
+            fn = N.lib().cvec_decode_indexed_dev if indexed else N.lib().cvec_decode_dev
             N.check(fn(C.byref(self.view), C.byref(chain), _ptr(out), _ptr(res), _ptr(status), _ptr(ws), ws.numel(),
                        _stream_ptr()))
-        self._index_valid = True
+        self._index_valid = indexed
         return res
 
     def decode(self, add_const=None, return_status=False):

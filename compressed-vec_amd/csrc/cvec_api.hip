@@ -29,7 +29,9 @@ struct MaskColumns {
     uint32_t k;
 };
 hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uint64_t *desc, const uint32_t *sec_res,
-                                 const int32_t *vstatus, uint32_t *valid, hipStream_t stream);
+                                 const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
+                                 hipStream_t stream);
+void set_read_path(int path);
 hipError_t launch_multi_and(const MaskColumns &cols, uint64_t n_rows, uint64_t n_slots0, uint8_t *out_masks,
                             uint16_t *popc, uint8_t *ended, uint64_t *per_row, uint32_t *row_sections,
                             uint64_t *result, hipStream_t stream);
@@ -397,6 +399,12 @@ cvec_status cvec_init(int device) {
     return static_scratch(&p); // this device's address of the static scratch, so that no later call has to look it up
 }
 
+cvec_status cvec_set_read_path(int32_t path) {
+    if (path != PATH_AUTO && path != PATH_SLOTS && path != PATH_VSTREAM) return CVEC_ERR_BAD_ARGUMENT;
+    set_read_path(path);
+    return CVEC_OK;
+}
+
 cvec_status cvec_timing_begin(int32_t max_records) {
     if (max_records <= 0 || max_records > 4096) return CVEC_ERR_BAD_ARGUMENT;
     HIP_TRY(timing_begin(max_records));
@@ -420,8 +428,9 @@ struct ReadWs {
     uint64_t *desc;
     uint32_t *sec_res;
     int32_t *vstatus;
-    uint64_t *scan; // 256 bytes or more of scratch: [0, 4) a spare result block, [8] the index tag
-    uint64_t *tag;  // whose section index the workspace holds (written by the index pass)
+    uint64_t *scan; // 256 bytes or more of scratch: [0, 4) a spare result block, [8] and [9] the two tag words
+    uint64_t *tag;  // [0] whose section index the workspace holds (written by the index pass, cleared by a
+                    // vector-streaming pass), [1] VS_MAGIC when the per-vector array holds valid-section counts
     size_t total;
 };
 static ReadWs carve_read_ws(void *base, uint64_t n_vectors, uint64_t n_sections) {
@@ -601,14 +610,14 @@ cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_si
 static_assert(CVEC_MAX_COLUMNS == CVEC_MAX_PRED_VALUES, "MaskColumns is sized by CVEC_MAX_PRED_VALUES");
 
 cvec_status cvec_valid_sections_dev(const cvec_dbatch_view *batch, const void *d_workspace, size_t workspace_bytes,
-                                    uint32_t *d_valid, void *stream) {
+                                    uint32_t *d_valid, uint8_t *d_parse_failed, void *stream) {
     cvec_status st = check_view(batch);
     if (st) return st;
     if (!d_workspace || (batch->n_vectors && !d_valid)) return CVEC_ERR_BAD_ARGUMENT;
     ReadWs w = carve_read_ws((void *)d_workspace, batch->n_vectors, batch->n_sections);
     if (w.total > workspace_bytes) return CVEC_ERR_WORKSPACE;
-    hipError_t e = launch_valid_sections(batch->d_sec_base, batch->n_vectors, w.desc, w.sec_res, w.vstatus, d_valid,
-                                         (hipStream_t)stream);
+    hipError_t e = launch_valid_sections(batch->d_sec_base, batch->n_vectors, w.desc, w.sec_res, w.vstatus, w.tag, d_valid,
+                                         d_parse_failed, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_valid_sections_dev");
     return CVEC_OK;
 }

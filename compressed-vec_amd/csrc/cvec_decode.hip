@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     if (v < CVEC_RESULT_WORDS) result[v] = 0; // k_finalize accumulates into it two launches later
     // Whose index this workspace holds from now on (a gated index is nobody's): a later pass that reuses
     // the descriptors instead of walking the headers again checks it.
-    if (v == 0) *tag = gate ? 0ull : cookie;
+    if (v == 0) { tag[0] = gate ? 0ull : cookie; tag[1] = 0; }
     if (v >= n) return;
     const uint64_t start = byte_off[v], L = byte_off[v + 1] - start;
     const uint64_t slot0 = sec_base[v], nslots = sec_base[v + 1] - slot0;
@@ -238,362 +238,11 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     vstatus[v] = st;
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_sections
-// ------------------------------------------------------------------------------------------------
-constexpr int TILE = 16; // sections per chunk: one per quad of lanes
-// Staging region of one wave: 18 KiB = 18 wave-wide 16-byte loads / LDS writes of 1 KiB; holds 16 worst-case
-// u32/f32 sections (1100 B) plus the vector headers between them.  Four waves per workgroup, two
-// workgroups per CU: 144 of the CU's 160 KiB.
-// A second shape, 12 KiB regions at three workgroups per CU, serves count-only passes over batches whose
-// sections are small enough that 16 of them still fit (dense integers, deltas): the octet loop is bound
-// by VALU issue, and a third wave per SIMD fills the slots that two leave empty (u32 dense 0.180 ->
-// 0.159 ms per GiB); 16 incompressible f32 sections do not fit 12 KiB and lose more lanes than that gains.
-constexpr int REGION_PIECES = 18;
-constexpr int REGION_PIECES_SMALL = 12;
+} // namespace cvec
 
-// The last 64 bytes of a region stay zero: sections without octets (Null, Const, skipped slots) run
-// the octet loop over them (32 empty octets), which keeps the loop free of per-kind masking.
-constexpr uint32_t region_span(int pieces) { return (uint32_t)pieces * 1024u - 64u; }
-constexpr int SEC_WAVES = 4;
-constexpr int SEC_THREADS = SEC_WAVES * 64;
+#include "cvec_sections.hpp"
 
-// MODE_FILTER_BITS: count only, one predicate value whose IEEE == is the same as equality of the bit
-// patterns (any integer; a float that is neither zero nor NaN): matching needs no compare instruction.
-enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2, MODE_FILTER_BITS = 3 };
-
-template <int PIECES>
-struct SecShared {
-    __attribute__((aligned(16))) uint8_t data[SEC_WAVES][PIECES * 1024];
-};
-
-typedef const __attribute__((address_space(3))) uint32_t *lds_u32p;
-
-// Misaligned LDS accesses take a slow path on gfx950 (~16x the cycles of an aligned one), so every
-// LDS read here is a single byte or naturally aligned dwords that are then funnel-shifted.
-template <int W>
-__device__ inline typename Elem<W>::U lds_load_unaligned(uint32_t addr) {
-    lds_u32p q = (lds_u32p)(uintptr_t)(addr & ~3u);
-    const uint32_t s = (addr & 3u) << 3;
-    if constexpr (W == 4) return __builtin_amdgcn_alignbit(q[1], q[0], s);
-    else return (uint64_t)__builtin_amdgcn_alignbit(q[1], q[0], s) |
-                ((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], s) << 32);
-}
-
-// NPRED = number of predicate values compared, a compile-time bucket (1, 2, 4, 8, 16): the values sit
-// in scalar registers and the compares are straight-line code.  (A run-time loop over pa.count reads
-// the values from the kernel arguments inside the octet loop, and the wait for those scalar loads is
-// the same counter the loop's LDS pipeline runs on: 3x slower for four values.)  The launcher pads
-// the list to the bucket with copies of its first value.
-template <int ETYPE, int NPRED>
-__device__ inline bool pred_match(const PredArgs &pa, typename Elem<(ETYPE == CVEC_U64 ? 8 : 4)>::U x) {
-    bool m = false;
-#pragma unroll
-    for (int p = 0; p < NPRED; p++) {
-        if constexpr (ETYPE == CVEC_F32) m |= __uint_as_float((uint32_t)x) == __uint_as_float((uint32_t)pa.v[p]); // IEEE ==
-        else if constexpr (ETYPE == CVEC_U32) m |= (uint32_t)x == (uint32_t)pa.v[p];
-        else m |= x == pa.v[p];
-    }
-    return m;
-}
-
-// Exact status of a section whose octet walk ran past its end or met an over-wide octet: the first
-// failing octet in the order of the reference's checks (src/nibblepack_simd.rs:515-557 for 32-bit
-// elements, src/nibblepacking.rs:474-500 for 64-bit): empty input, length < 3, n > 8, payload too
-// long.  Rare path (malformed input only); plain byte reads.
-template <int W>
-__device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, uint32_t end, bool raw) {
-    for (int k = 0; k < FIXED_LEN / 8; k++) {
-        const int rem = (int)end - (int)p;
-        if (rem == 0 && raw) return 0; // a stream's last block may hold fewer than 32 octets
-        if (rem <= 0) return CVEC_NOT_ENOUGH_SPACE;
-        const uint32_t mask = data[p];
-        if (mask == 0) { p += 1; continue; }
-        if (W == 4 && rem < 3) return CVEC_NOT_ENOUGH_SPACE;
-        if (rem < 2) return CVEC_NOT_ENOUGH_SPACE;
-        const uint32_t hn = (uint32_t)data[p + 1] >> 4;
-        if (W == 4 && hn > 7) return CVEC_INVALID_FORMAT;
-        const int size = (int)(2 + (((hn + 1) * __popc(mask) + 1) >> 1));
-        if (size > rem) return CVEC_NOT_ENOUGH_SPACE;
-        p += size;
-    }
-    return 0;
-}
-
-// One chunk (up to 16 sections staged in the wave's LDS region) by one wave.  Lane = 4*sec + q: the
-// four lanes of a quad walk the octets of section `sec` together (same addresses: LDS broadcasts)
-// and lane q extracts elements 2q and 2q+1 of every octet, so nothing has to cross lanes and no
-// octet table is needed.  A step of the loop handles octet k of all 16 sections:
-//   - the walk chain: two byte reads (always aligned), octet size, next cursor; the reads of the
-//     next octet are issued as soon as the cursor is known,
-//   - in the shadow of that latency the two fields of the current octet are pulled out of the
-//     bitstream with aligned dword reads and funnel shifts (plain bitstream rule of the format,
-//     reference src/nibblepacking.rs:436-470, src/nibblepack_simd.rs:571-585), run through the
-//     XorSink state (kept in registers: octet k of a lane XORs onto octet k-1 of the same lane,
-//     src/sink.rs:271-275, src/section.rs:707) or the Delta base add (src/section.rs:636-641) and
-//     the fused epilogue.
-// Section kinds are folded into the same loop: a Null or Const section runs it with every mask
-// forced to 0 and its value preloaded into the XOR state / the base.
-//
-// CAREFUL = false is the common path: it assumes that no stored octet of a 32-bit section claims
-// more than 8 nibbles or 8 or more trailing zero nibbles (never produced by an encoder: the value
-// would not fit 32 bits) and only records whether one did; the caller then repeats the chunk with
-// CAREFUL = true, which handles both exactly.  Returns that record.
-template <int ETYPE, int MODE, int NPRED, bool CAREFUL, int PIECES>
-__device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
-                                              uint32_t len, bool live, uint64_t slot, int lane, const PredArgs &pa,
-                                              const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
-                                              uint32_t &mask_hi, void *__restrict__ out_) {
-    constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
-    using U = typename Elem<W>::U;
-    const uint32_t q = lane & 3;
-    const bool isoct = live && (kind == K_NP || kind == K_DELTA || kind == K_XOR || kind == K_RAW);
-    const bool isconst = live && kind == K_CONST, isdelta = live && kind == K_DELTA;
-    const bool zeroes = kind == K_NULL; // the section reaches the sink through process_zeroes()
-    const uint32_t end = rel + len;
-    const uint32_t p0 = isoct ? rel + (kind == K_DELTA ? DELTA_HDR : (kind == K_RAW ? 0u : 3u)) : region_span(PIECES);
-    // Const value (section byte 1) or Delta base (section byte 4)
-    U v = 0;
-    if (isconst || isdelta) v = lds_load_unaligned<W>(lds_base + rel + (isconst ? 1u : 4u));
-    U st0 = 0, st1 = 0; // XOR state of the lane's two element columns / the additive base
-    if constexpr (ETYPE == CVEC_F32) { st0 = st1 = isconst ? v : (U)0; }
-    const U base = (isconst || isdelta) ? v : (U)0;
-    // MODE_FILTER_BITS: the predicate's bits are XORed into the state (f32) or moved to the other side of
-    // the Delta add (integers), so that an element matches iff its word is zero
-    U tgt = 0;
-    if constexpr (MODE == MODE_FILTER_BITS) {
-        if constexpr (ETYPE == CVEC_F32) { st0 ^= (U)pa.v[0]; st1 = st0; }
-        else tgt = (U)pa.v[0] - base;
-    }
-    uint32_t mism = 0;
-    mask_lo = 0; mask_hi = 0;
-    const uint32_t lowmask = (1u << (2 * q)) - 1u;
-    uint32_t cnt = 0, hmax = 0, racc = 0;
-    const uint32_t q2 = 2 * q;
-    // MODE_DECODE output: a buffer descriptor over the chunk's 16 section slots of `out`, the lane's
-    // byte offset in it (its section, elements 2q and 2q+1 of octet 0), out of range for lanes that
-    // store nothing
-    const uint64_t dslot = slot - ((uint32_t)lane >> 2); // the chunk's first slot, in every lane
-    const uint64_t slot0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dslot >> 32)) << 32) |
-                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dslot);
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((U *)out_ + slot0 * FIXED_LEN), 0,
-                                                         MODE == MODE_DECODE ? TILE * FIXED_LEN * W : 0, 0x00020000);
-    const uint32_t ooff = (live && kind != K_SKIP && kind != K_ILLEGAL)
-                              ? (((uint32_t)lane >> 2) * FIXED_LEN + 2 * q) * (uint32_t)W : 0x7ffff000u;
-    const bool addc = sa.add_const != 0;
-
-    // The loop is software-pipelined by one octet: iteration k runs the front half of octet k (walk
-    // chain, header reads of octet k+1, address + reads of the lane's fields, per-octet constants) and
-    // the back half of octet k-1 (extraction, XOR / Delta, epilogue), so every LDS read has a whole
-    // iteration to land and the serial chain header -> size -> next header is as short as it can be.
-    // All LDS reads are inline asm with counted waits (LDS returns in order): per iteration the wave
-    // issues 2 header reads, then NDATA field reads.
-    constexpr int NDATA = W == 4 ? 2 : 3;
-    struct Oct { // what the back half needs of an octet
-        uint64_t d01, d23;
-        uint32_t d2, d4, s, sh1, sm0, sm1, t4;
-        U fm;
-    };
-    uint32_t pa_ = lds_base + p0;
-    uint32_t mask, nw;
-    asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %2 offset:1\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(mask), "=&v"(nw)
-                 : "v"(pa_)
-                 : "memory");
-
-    // front half of the octet whose header is in (mask, nw); leaves the next header in flight
-    auto front = [&](Oct &o, uint32_t &mask_n, uint32_t &nw_n) {
-        // ---- walk chain: octet bytes = 1 if mask == 0, else 2 + (n*cnt + 1)/2; then the reads of the
-        //      next octet's header (after the last octet: a harmless read of the bytes that follow) ------
-        //      in eighths of a byte with the field width n4 = 4n that the extraction needs anyway:
-        //      (n4 * cnt + 20) / 8 = 2 + (n * cnt + 1) / 2, and 8 / 8 for the empty octet
-        uint32_t n4;                        // field width in bits, 4 * ((nw >> 4) + 1), as ONE instruction
-        asm("v_lshl_add_u32 %0, %1, 2, 4" : "=v"(n4) : "v"(nw >> 4));
-        const uint32_t pc = __popc(mask);
-        const uint32_t pa_cur = pa_;
-        pa_ += ((uint32_t)__umul24(n4, pc) + (mask ? 20u : 8u)) >> 3;
-        // mask and nw pass through the statement so that everything below is scheduled behind it
-        asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %4 offset:1"
-                     : "=&v"(mask_n), "=&v"(nw_n), "+v"(mask), "+v"(nw)
-                     : "v"(pa_)
-                     : "memory");
-        // ---- address of the lane's two fields, their reads ---------------------------------------------
-        // bit address of the first field: behind the two header bytes, idx fields of n4 bits further on
-        const uint32_t B = (uint32_t)__umul24(__popc(mask & lowmask), n4) + ((pa_cur << 3) + 16u);
-        o.s = B; // funnel shift; only bits 4:0 are used
-        const uint32_t qa = (B >> 3) & ~3u;
-        if constexpr (W == 4) {
-            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8"
-                         : "=&v"(o.d01), "=&v"(o.d2)
-                         : "v"(qa)
-                         : "memory");
-        } else {
-            asm volatile("ds_read2_b32 %0, %3 offset1:1\n\tds_read2_b32 %1, %3 offset0:2 offset1:3\n\tds_read_b32 %2, %3 offset:16"
-                         : "=&v"(o.d01), "=&v"(o.d23), "=&v"(o.d4)
-                         : "v"(qa)
-                         : "memory");
-        }
-        // ---- per-octet constants ---------------------------------------------------------------------------
-        if constexpr (W == 4 && CAREFUL) hmax = max(hmax, mask ? (nw >> 4) : 0u);
-        o.t4 = nw << 2; // trailing zero bits (a 32-bit shift uses bits 4:0 of its count; bits 5:4 only matter to CAREFUL and 64-bit)
-        o.sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
-        o.sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
-        if constexpr (W == 4 && !CAREFUL) racc |= nw & (o.sm0 | o.sm1); // the quad's lanes cover every stored element
-        o.sh1 = n4 & o.sm0; // the second field lies n4 bits further on if the first one is stored
-        if constexpr (W == 4) {
-            // a left shift of 32 or more clears the lane, as the AVX2 variable shift of the reference does
-            o.fm = (CAREFUL && (nw & 8u)) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
-        } else {
-            o.fm = ~0ull >> ((64u - n4) & 63u);
-        }
-    };
-
-    constexpr int HOLD = 4; // octets of decoded values held back per store burst (MODE_DECODE)
-    U hold[2 * HOLD];
-    // back half of octet k: `newer` LDS reads were issued after its field reads
-    auto back = [&](Oct &o, int k, auto newer) {
-        U x0, x1;
-        if constexpr (W == 4) {
-            // the octet's values pass through the wait: the compiler may neither use the loaded registers
-            // ahead of it nor move the extraction somewhere else
-            asm volatile("s_waitcnt lgkmcnt(%c9)"
-                         : "+v"(o.d01), "+v"(o.d2), "+v"(o.fm), "+v"(o.sh1), "+v"(o.sm0), "+v"(o.sm1), "+v"(o.s), "+v"(o.t4),
-                           "+v"(racc)
-                         : "i"(decltype(newer)::value)
-                         : "memory");
-            const uint32_t d0 = (uint32_t)o.d01, d1 = (uint32_t)(o.d01 >> 32);
-            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, o.s), hi = __builtin_amdgcn_alignbit(o.d2, d1, o.s);
-            const uint32_t w1 = (uint32_t)((((uint64_t)hi << 32) | lo) >> o.sh1);
-            x0 = ((lo & o.fm) & o.sm0) << (o.t4 & 31u);
-            x1 = ((w1 & o.fm) & o.sm1) << (o.t4 & 31u);
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(%c7)"
-                         : "+v"(o.d01), "+v"(o.d23), "+v"(o.d4), "+v"(o.fm), "+v"(o.sh1), "+v"(o.sm0), "+v"(o.sm1)
-                         : "i"(decltype(newer)::value)
-                         : "memory");
-            const uint32_t d0 = (uint32_t)o.d01, d1 = (uint32_t)(o.d01 >> 32), d2 = (uint32_t)o.d23,
-                           d3 = (uint32_t)(o.d23 >> 32);
-            const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, o.s), w1 = __builtin_amdgcn_alignbit(d2, d1, o.s),
-                           w2 = __builtin_amdgcn_alignbit(d3, d2, o.s), w3 = __builtin_amdgcn_alignbit(o.d4, d3, o.s);
-            const uint64_t f0 = ((uint64_t)w1 << 32) | w0;
-            const unsigned __int128 win = ((unsigned __int128)(((uint64_t)w3 << 32) | w2) << 64) | f0;
-            const uint64_t f1 = (uint64_t)(win >> o.sh1);
-            x0 = ((f0 & o.fm) & (uint64_t)(int64_t)(int32_t)o.sm0) << (o.t4 & 60u);
-            x1 = ((f1 & o.fm) & (uint64_t)(int64_t)(int32_t)o.sm1) << (o.t4 & 60u);
-        }
-        if constexpr (MODE == MODE_FILTER_BITS) {
-            if constexpr (ETYPE == CVEC_F32) { st0 ^= x0; st1 ^= x1; x0 = st0; x1 = st1; }
-            else { x0 ^= tgt; x1 ^= tgt; }
-            // zero word = match: count the mismatches (min(x, 1)), no compare / carry instructions
-            // (as asm: the compiler rewrites min(x, 1) into a compare + select + add-with-carry chain)
-            uint32_t w0, w1, m0, m1;
-            if constexpr (W == 4) { w0 = (uint32_t)x0; w1 = (uint32_t)x1; }
-            else { w0 = (uint32_t)x0 | (uint32_t)(x0 >> 32); w1 = (uint32_t)x1 | (uint32_t)(x1 >> 32); }
-            asm("v_min_u32 %0, 1, %1" : "=v"(m0) : "v"(w0));
-            asm("v_min_u32 %0, 1, %1" : "=v"(m1) : "v"(w1));
-            mism += m0 + m1;
-            return;
-        }
-        if constexpr (ETYPE == CVEC_F32) {
-            st0 ^= x0; st1 ^= x1;
-            x0 = st0; x1 = st1;
-        } else {
-            x0 += base; x1 += base;
-        }
-        // ---- epilogue ----------------------------------------------------------------------------------------
-        if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
-            const bool m0 = pred_match<ETYPE, NPRED>(pa, x0), m1 = pred_match<ETYPE, NPRED>(pa, x1);
-            cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
-            if constexpr (MODE == MODE_FILTER_MASKS) {
-                // byte k of the section's mask: bits 2q, 2q+1 from each lane of the quad
-                uint32_t bits = zeroes ? (pa.match_zero ? 3u : 0u) : ((m0 ? 1u : 0u) | (m1 ? 2u : 0u));
-                if (kind == K_GATED) bits = 0;
-                bits <<= 2 * q;
-                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
-                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
-                // lane q of the quad collects mask bytes 4q..4q+3 and 16+4q..16+4q+3 (dwords q and 4+q of
-                // the section's mask); the caller stores them once per chunk
-                const uint32_t mine = q == (uint32_t)((k >> 2) & 3) ? bits : 0u;
-                if (k < 16) mask_lo |= mine << (8 * (k & 3)); else mask_hi |= mine << (8 * (k & 3));
-            }
-        } else {
-            if (addc) {
-                // AddConstSink in front of VecSink (src/sink.rs:304-317): process_zeroes forwards the
-                // base itself; everything else is x + base (f32: IEEE add, ints: wrapping).
-                if constexpr (ETYPE == CVEC_F32) {
-                    const float bf = __uint_as_float((uint32_t)sa.base);
-                    x0 = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x0) + bf);
-                    x1 = zeroes ? (uint32_t)sa.base : __float_as_uint(__uint_as_float(x1) + bf);
-                } else {
-                    x0 += (U)sa.base; x1 += (U)sa.base;
-                }
-            }
-            // The lane's 8 or 16 bytes are a quarter of a 32- or 64-byte piece of the output; four octets
-            // are held back and stored together, so that the pieces of one 128-byte line leave the wave
-            // within a few cycles of each other (spread over the octet loop they reach memory as partial
-            // line writes: 3.4 TB/s instead of 4.9 for the same pattern issued back to back).
-            // The stores are unconditional buffer stores (lanes without output aim past the end of the
-            // descriptor and are dropped): straight-line code lets the compiler count them, so the wait
-            // for the next chunk's prefetched bytes does not also wait for this chunk's stores.
-            hold[2 * (k % HOLD)] = x0;
-            hold[2 * (k % HOLD) + 1] = x1;
-            if (k % HOLD == HOLD - 1) {
-#pragma unroll
-                for (int j = 0; j < HOLD; j++) {
-                    const U y0 = hold[2 * j], y1 = hold[2 * j + 1];
-                    const uint32_t at = ooff + (uint32_t)(8 * (k - (HOLD - 1) + j) * W);
-                    if constexpr (W == 4) {
-                        typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{y0, y1}, orsrc, at, 0, 0);
-                    } else {
-                        typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)}, orsrc, at, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-
-    Oct prev, cur;
-    uint32_t mask_n, nw_n;
-    front(prev, mask_n, nw_n);
-    asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(mask_n), "+v"(nw_n) : "i"(NDATA) : "memory"); // header of octet 1
-    mask = mask_n; nw = nw_n;
-    // Fully unrolled on purpose: the field reads of an octet are in flight from one iteration to the
-    // next, and only straight-line code guarantees that the compiler never copies a register (a loop
-    // back-edge copy) whose asm load has not landed yet.
-#pragma unroll
-    for (int k = 1; k < FIXED_LEN / 8; k++) {
-        front(cur, mask_n, nw_n);
-        // octet k-1: behind its field reads came 2 header reads and NDATA field reads
-        back(prev, k - 1, std::integral_constant<int, 2 + NDATA>());
-        prev = cur;
-        // the next header has landed once only this iteration's field reads are outstanding; the
-        // step's results pass through the wait so that the work above is issued ahead of it
-        asm volatile("s_waitcnt lgkmcnt(%c6)" : "+v"(mask_n), "+v"(nw_n), "+v"(cnt), "+v"(mism), "+v"(st0), "+v"(st1) : "i"(NDATA) : "memory");
-        mask = mask_n; nw = nw_n;
-    }
-    back(prev, FIXED_LEN / 8 - 1, std::integral_constant<int, 0>());
-    // ---- per-section result ------------------------------------------------------------------------------------
-    uint32_t status = 0;
-    if (kind == K_ILLEGAL) status = CVEC_INVALID_FORMAT;
-    const uint32_t p_end = pa_ - lds_base;
-    if (isoct && (p_end > end || (W == 4 && CAREFUL && hmax > 7))) status = walk_status<W>(data, p0, end, kind == K_RAW);
-    uint32_t count;
-    if constexpr (MODE == MODE_DECODE) {
-        count = FIXED_LEN;
-    } else {
-        if constexpr (MODE == MODE_FILTER_BITS) cnt = 2 * (FIXED_LEN / 8) - mism; // the lane saw 64 elements
-        cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
-        cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
-        // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
-        count = zeroes ? (pa.match_zero ? FIXED_LEN : 0) : cnt;
-        if (kind == K_GATED) count = 0;
-    }
-    sec_result = kind == K_SKIP ? res_pack(0, 0) : (status ? res_pack(0, status) : res_pack(count, 0));
-    return isoct && (racc & 0x88u) != 0;
-}
+namespace cvec {
 
 // Plan of one chunk: the longest run of sections from s whose span fits a staging region.
 struct ChunkPlan {
@@ -795,12 +444,17 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
 #else
         } else if (cur.n != 0) {
 #endif
-            const bool odd = process_chunk<ETYPE, MODE, NPRED, false, PIECES>(data, lds_base, cur.kind, cur.rel, cur.len,
-                                                                      sec < cur.n, s_cur + sec, lane, pa, sa, res_word,
-                                                                      mk_lo, mk_hi, out_);
-            if (__ballot(odd) != 0)
-                process_chunk<ETYPE, MODE, NPRED, true, PIECES>(data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n,
-                                                        s_cur + sec, lane, pa, sa, res_word, mk_lo, mk_hi, out_);
+            uint32_t ooff;
+            const out_rsrc_t orsrc = chunk_out_rsrc<W, MODE>(out_, s_cur + sec, lane, ooff);
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES)>(
+                data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff);
+            if constexpr (W == 4) {
+                const unsigned long long odd_m = __ballot(odd); // a lane only sees the octets that store its own elements
+                if (odd_m != 0) {
+                    if ((odd_m >> ((uint32_t)lane & ~3u)) & 0xfull) section_exact<ETYPE, MODE, NPRED>(data, lds_base, cur.kind, cur.rel, cur.len, lane, pa, sa, res_word,
+                                                               mk_lo, mk_hi, orsrc, ooff);
+                }
+            }
             res_slot = s_cur + sec;
             res_pending = sec < cur.n && (lane & 3) == 0;
             mk_pending = sec < cur.n && cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
@@ -1028,6 +682,14 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
 // phase: READ_ALL = index, sections, finalize; READ_INDEX_ONLY = the index pass alone (descriptors and
 // per-vector header statuses stay in the caller's workspace); READ_INDEXED = sections + finalize over
 // descriptors that an earlier call left there.
+// cvec_vstream.hip
+bool vstream_eligible(int mode, const cvec_dbatch_view &b, bool forced);
+hipError_t launch_vstream(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint32_t *nvalid,
+                          uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
+                          uint64_t *tag, hipStream_t stream);
+static int g_read_path = PATH_AUTO;
+void set_read_path(int path) { g_read_path = path; }
+
 template <int ETYPE>
 static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                           uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
@@ -1041,6 +703,20 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     cookie |= 1;
     const uint64_t *check = phase == READ_INDEXED ? tag : nullptr;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
+    if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS &&
+        vstream_eligible(mode, b, g_read_path == PATH_VSTREAM)) {
+        // many short vectors: one kernel, no section index, no per-section results (the timing slots of the
+        // index and finalize kernels hold the memset and nothing)
+        timer_mark(rec, 0, stream);
+        (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
+        timer_mark(rec, 1, stream);
+        timer_mark(rec, 2, stream);
+        (void)launch_vstream(mode, b, pa, sa, (uint32_t *)vstatus, d_result, d_per_vector, d_status, d_masks, d_out, tag, stream);
+        timer_mark(rec, 3, stream);
+        timer_mark(rec, 4, stream);
+        timer_mark(rec, 5, stream);
+        return;
+    }
     timer_mark(rec, 0, stream);
     if (phase != READ_INDEXED)
         k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,

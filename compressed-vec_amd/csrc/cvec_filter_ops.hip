@@ -26,15 +26,28 @@ __global__ __launch_bounds__(256) void k_valid_sections(const uint64_t *__restri
                                                         const uint64_t *__restrict__ desc,
                                                         const uint32_t *__restrict__ sec_res,
                                                         const int32_t *__restrict__ vstatus,
-                                                        uint32_t *__restrict__ valid) {
-    (void)vstatus; // a vector that failed its header checks has only K_SKIP slots: nothing more to look up
+                                                        const uint64_t *__restrict__ tag,
+                                                        uint32_t *__restrict__ valid, uint8_t *__restrict__ parse_failed) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
+    // after a vector-streaming pass the per-vector array holds these counts themselves (bit 31: the vector
+    // ended at a header that did not parse)
+    if (tag[1] == VS_MAGIC) {
+        const uint32_t x = (uint32_t)vstatus[v];
+        valid[v] = x & 0x7fffffffu;
+        if (parse_failed) parse_failed[v] = (uint8_t)(x >> 31);
+        return;
+    }
+    // a vector that failed its header checks has only K_SKIP slots
     const uint64_t a = sec_base[v], b = sec_base[v + 1];
     uint64_t s = a;
-    for (; s < b; s++)
-        if (desc_kind(desc[s]) == K_SKIP || (sec_res[s] >> 16) != 0) break;
+    bool decode_error = false;
+    for (; s < b; s++) {
+        if (desc_kind(desc[s]) == K_SKIP) break;
+        if ((sec_res[s] >> 16) != 0) { decode_error = true; break; }
+    }
     valid[v] = (uint32_t)(s - a);
+    if (parse_failed) parse_failed[v] = (!decode_error && vstatus[v] != 0) ? 1 : 0;
 }
 
 struct MaskColumns {
@@ -152,8 +165,11 @@ __global__ void k_pos_off(const uint64_t *__restrict__ sec_base, uint64_t n, con
 
 // ---- launchers ----------------------------------------------------------------------------------------
 hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uint64_t *desc, const uint32_t *sec_res,
-                                 const int32_t *vstatus, uint32_t *valid, hipStream_t stream) {
-    if (n) k_valid_sections<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(sec_base, n, desc, sec_res, vstatus, valid);
+                                 const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
+                                 hipStream_t stream) {
+    if (n)
+        k_valid_sections<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(sec_base, n, desc, sec_res, vstatus, tag, valid,
+                                                                          parse_failed);
     return hipGetLastError();
 }
 

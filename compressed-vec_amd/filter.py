@@ -48,11 +48,10 @@ class VectorFilter:
             if status[0] != N.OK:
                 # A section that fails to decode ends the iteration silently (src/filter.rs:226); a
                 # section header that fails to parse is a panic in the reference (src/filter.rs:221).
-                res = dev.section_results()
-                bad = np.nonzero(res >> 16)[0]
-                if bad.size == 0:
+                valid, parse_failed = dev.valid_sections()
+                if parse_failed[0]:
                     raise N.CodingError(int(status[0]))
-                m = m[:int(bad[0])]
+                m = m[:int(valid[0])]
             self._masks = m
             self._count = total
             self._status = int(status[0])

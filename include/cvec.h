@@ -117,6 +117,20 @@ const char *cvec_status_name(cvec_status s);
 cvec_status cvec_timing_begin(int32_t max_records);
 cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_finalize, int32_t *n_records);
 
+/* Which kernel serves cvec_filter_count_dev / cvec_decode_dev (and the *_batch calls built on them).  No
+ * counterpart in the reference.  Two kernels produce identical results:
+ *   CVEC_PATH_SLOTS    an index pass walks the section headers of every vector, then a kernel decodes 16
+ *                      consecutive sections per wavefront pass, then a pass folds per-vector results:
+ *                      parallel over sections, any batch shape;
+ *   CVEC_PATH_VSTREAM  one kernel; 16 vectors per wavefront side by side, the section chain followed in LDS:
+ *                      parallel over vectors, no index, each byte read once (u32 / f32, blob < 4 GiB).
+ * CVEC_PATH_AUTO (default) picks VSTREAM for sparse batches (at least 16384 vectors, at most 64 sections per
+ * vector and 48 bytes per section on average: mostly Null / Const sections), SLOTS otherwise.  Forcing VSTREAM applies wherever the batch is eligible at all
+ * (gated and indexed passes, u64 batches and blobs of 4 GiB or more always take SLOTS).  Process-wide;
+ * meant for tests and measurements. */
+enum { CVEC_PATH_AUTO = 0, CVEC_PATH_SLOTS = 1, CVEC_PATH_VSTREAM = 2 };
+cvec_status cvec_set_read_path(int32_t path);
+
 /* ---- device-resident operations ----------------------------------------------------------- */
 
 /* Bytes of scratch the _dev operations need for a batch of this shape. */
@@ -171,9 +185,8 @@ cvec_status cvec_filter_count_gated_dev(const cvec_dbatch_view *batch, const cve
  * section slot + one header status per vector).  These two calls split that: cvec_index_dev runs the
  * walk alone, and cvec_filter_count_indexed_dev is cvec_filter_count_dev without it, over the index
  * that the workspace still holds.  The caller guarantees that the workspace was last written by
- * cvec_index_dev, cvec_filter_count_dev, cvec_filter_count_indexed_dev or cvec_decode_dev on this
- * same batch (an ungated pass: a gated one leaves gated descriptors behind) and that the batch has
- * not changed since.  Results are identical to cvec_filter_count_dev's; with d_gate (may be NULL)
+ * cvec_index_dev, cvec_filter_count_indexed_dev or cvec_decode_indexed_dev on this same batch and that the
+ * batch has not changed since (any other call that uses the workspace may leave it without an index).  Results are identical to cvec_filter_count_dev's; with d_gate (may be NULL)
  * they are cvec_filter_count_gated_dev's: the section kernel itself looks at the gate masks, the
  * index stays the ungated one and remains valid.  The index pass tags the
  * workspace with the batch it belongs to (pointers and shape); an indexed call over a workspace that
@@ -201,9 +214,11 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
 /* The number of leading sections of every vector that the last cvec_filter_count_dev /
  * cvec_decode_dev on `batch` with this workspace produced: the reference's section iteration ends
  * at the first section that fails to decode (src/filter.rs:226) or to parse.  d_valid: n_vectors
- * u32.  Masks / decoded data of later sections are unspecified. */
+ * u32.  Masks / decoded data of later sections are unspecified.  d_parse_failed (nullable): n_vectors
+ * bytes, 1 where the iteration ended at the vector's header checks or at a section header that does not
+ * parse (where the reference's VectorFilter panics, src/filter.rs:221, instead of just ending). */
 cvec_status cvec_valid_sections_dev(const cvec_dbatch_view *batch, const void *d_workspace, size_t workspace_bytes,
-                                    uint32_t *d_valid, void *stream);
+                                    uint32_t *d_valid, uint8_t *d_parse_failed, void *stream);
 
 /* One filtered vector column: the masks cvec_filter_count_dev wrote for a batch, that batch's
  * sec_base and the valid-section counts from cvec_valid_sections_dev. */

@@ -46,18 +46,24 @@ def run(name, tname, kind, nvec, length, pred, add_const):
     batch = cv.encode_device(tname, vals, eo)
     t_enc = timed(lambda: cv.encode_device(tname, vals, eo), 5)
     out = torch.empty(batch.n_sections * 256, dtype=vals.dtype, device="cuda")
-    t_dec = timed(lambda: batch.decode_async(out, add_const=add_const))
     res = batch.result_buffer()
     p = cv.make_pred(batch.etype, pred)
-    t_fil = timed(lambda: batch.filter_count_async(p, result=res))
-    got = int(res[0].item())
     want = int((vals == pred).sum().item())
-    if kind != "f32_xor":                       # (10000-element f32 vectors: the zero padding never matches these predicates either)
-        assert got == want, (got, want)
-    print(json.dumps({"config": name, "vectors": nvec, "vector_len": length, "raw_MiB": raw >> 20,
-                      "compressed_B_per_elem": round(batch.n_bytes / vals.numel(), 3),
-                      "encode_GBs": round(raw / t_enc / 1e9, 1), "decode_GBs": round(raw / t_dec / 1e9, 1),
-                      "filter_GBs": round(raw / t_fil / 1e9, 1), "filter_matches": got}), flush=True)
+    rec = {"config": name, "vectors": nvec, "vector_len": length, "raw_MiB": raw >> 20,
+           "compressed_B_per_elem": round(batch.n_bytes / vals.numel(), 3), "encode_GBs": round(raw / t_enc / 1e9, 1)}
+    # both read kernels (cvec_set_read_path): 1 = index + section-slot + finalize, 2 = vector-streaming; 0 = the library's choice
+    for path, tag in ((1, "slots"), (2, "vstream"), (0, "auto")):
+        assert cv.lib().cvec_set_read_path(path) == 0
+        t_dec = timed(lambda: batch.decode_async(out, add_const=add_const))
+        t_fil = timed(lambda: batch.filter_count_async(p, result=res), 20)
+        got = int(res[0].item())
+        if kind != "f32_xor":                   # (10000-element f32 vectors: the zero padding never matches these predicates either)
+            assert got == want, (got, want)
+        rec["decode_GBs_" + tag] = round(raw / t_dec / 1e9, 1)
+        rec["filter_GBs_" + tag] = round(raw / t_fil / 1e9, 1)
+        rec["filter_ms_" + tag] = round(t_fil * 1e3, 4)
+    rec["filter_matches"] = got
+    print(json.dumps(rec), flush=True)
 
 
 def run_streams(nstreams, length):
@@ -89,4 +95,5 @@ if __name__ == "__main__":
     run("cfg4 u64 delta", "u64", "u64_delta", n // 2, 10000, 100003, 5)
     # aperiodic f32 (SplitMix64, 12 mantissa bits) at the benchmark's vector shape
     run("cfg5 f32 splitmix", "f32", "f32_splitmix", 131072, 2048, None, 2.5)
+    run("cfg5 f32 sinusoid", "f32", "f32_xor", 131072, 2048, 3.0, 2.5)
     run_streams(n // 2, 10000)

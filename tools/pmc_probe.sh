@@ -1,0 +1,14 @@
+#!/bin/bash
+# Runs on the GPU box: PMC passes over tools/vstream_probe.py (each counter set in its own rocprofv3 run).
+# usage: tools/pmc_probe.sh <tag> [probe args...]; output under gpurun_out/<tag>_*; summarise with tools/pmc_summary.py
+set -e
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+run() { # name, counters
+  timeout -s KILL 120 rocprofv3 --pmc $2 -d $R/gpurun_out/${TAG}_$1 -o pmc --output-format csv -- python3 $R/tools/vstream_probe.py "${@:3}" > $R/gpurun_out/${TAG}_$1.log 2>&1
+}
+run fetch "FETCH_SIZE" "$@"
+run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "$@"
+run sq2 "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM" "$@"
+run tcc "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "$@"
