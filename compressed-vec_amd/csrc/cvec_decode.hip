@@ -703,19 +703,22 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     cookie |= 1;
     const uint64_t *check = phase == READ_INDEXED ? tag : nullptr;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
-    if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS &&
-        vstream_eligible(mode, b, g_read_path == PATH_VSTREAM)) {
-        // many short vectors: one kernel, no section index, no per-section results (the timing slots of the
-        // index and finalize kernels hold the memset and nothing)
-        timer_mark(rec, 0, stream);
-        (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
-        timer_mark(rec, 1, stream);
-        timer_mark(rec, 2, stream);
-        (void)launch_vstream(mode, b, pa, sa, (uint32_t *)vstatus, d_result, d_per_vector, d_status, d_masks, d_out, tag, stream);
-        timer_mark(rec, 3, stream);
-        timer_mark(rec, 4, stream);
-        timer_mark(rec, 5, stream);
-        return;
+    if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS) {
+        // sparse batches of many vectors: one kernel, no section index, no per-section results (the timing slots of
+        // the index and finalize kernels hold the memset and nothing)
+        const bool vs = g_read_path == PATH_VSTREAM ? vstream_eligible(mode, b, true)
+                                                    : (g_read_path == PATH_AUTO && vstream_eligible(mode, b, false));
+        if (vs) {
+            timer_mark(rec, 0, stream);
+            (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
+            timer_mark(rec, 1, stream);
+            timer_mark(rec, 2, stream);
+            (void)launch_vstream(mode, b, pa, sa, (uint32_t *)vstatus, d_result, d_per_vector, d_status, d_masks, d_out, tag, stream);
+            timer_mark(rec, 3, stream);
+            timer_mark(rec, 4, stream);
+            timer_mark(rec, 5, stream);
+            return;
+        }
     }
     timer_mark(rec, 0, stream);
     if (phase != READ_INDEXED)

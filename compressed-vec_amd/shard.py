@@ -37,3 +37,90 @@ def allreduce_counts(counts):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
+
+
+class CountBucketRing:
+    """Result blocks of consecutive query steps, all-reduced in buckets.
+
+    Every step writes its result block (`words` int64: total count, failed vectors, ...) into the next
+    row of a bucket; a full bucket of `bucket` rows goes out as ONE asynchronous all-reduce, beside the
+    kernels of the following steps.  `nbuckets` buckets rotate; a bucket is written again only after its
+    last reduction has been waited for.  drain() reduces the partial bucket of the last steps (rows not
+    written since the bucket's last reduction are zeroed first) and waits for everything, so after it
+    every step's counts are global sums.  Works on CUDA tensors over RCCL and on CPU tensors over gloo.
+
+    `streams`: the torch.cuda streams steps are enqueued on (step i on stream i % len); None on the CPU
+    and for a single-stream caller.  `reduce=False` keeps the bookkeeping and skips the collectives
+    (one rank)."""
+
+    def __init__(self, words, device, bucket=8, nbuckets=3, streams=None, reduce=True):
+        import torch
+        self.bucket, self.nbuckets = bucket, nbuckets
+        self.buckets = [torch.zeros(bucket, words, dtype=torch.int64, device=device) for _ in range(nbuckets)]
+        self.rows = [self.buckets[k][j] for k in range(nbuckets) for j in range(bucket)]
+        self.ring = bucket * nbuckets
+        self.pending = [None] * nbuckets
+        self.streams = list(streams) if streams else []
+        self.reduce = reduce
+        self.i = 0
+        self.collectives = 0
+
+    def _stream(self, idx):
+        import contextlib
+        import torch
+        return torch.cuda.stream(self.streams[idx]) if self.streams else contextlib.nullcontext()
+
+    def _wait(self, k):
+        if self.pending[k] is None:
+            return
+        if self.streams:                    # a stream-side wait on every stream that will write the bucket
+            for idx in range(len(self.streams)):
+                with self._stream(idx):
+                    self.pending[k].wait()
+        else:
+            self.pending[k].wait()
+        self.pending[k] = None
+
+    def _all_reduce(self, k, on_stream):
+        import torch.distributed as dist
+        if self.streams:                    # the bucket's other steps may be on other streams
+            for idx, st in enumerate(self.streams):
+                if idx != on_stream:
+                    self.streams[on_stream].wait_stream(st)
+        with self._stream(on_stream):
+            self.pending[k] = dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, async_op=True)
+        self.collectives += 1
+
+    def begin_step(self):
+        """The row the next step writes, and the index of the stream to enqueue it on."""
+        j = self.i % self.ring
+        if j % self.bucket == 0:            # first step into a bucket: its last reduction must be over
+            self._wait(j // self.bucket)
+        return self.rows[j], (self.i % len(self.streams) if self.streams else 0)
+
+    def end_step(self):
+        """After the step has been enqueued: a full bucket goes out.  Returns the step's row index."""
+        j = self.i % self.ring
+        on_stream = self.i % len(self.streams) if self.streams else 0
+        self.i += 1
+        if self.reduce and j % self.bucket == self.bucket - 1:
+            self._all_reduce(j // self.bucket, on_stream)
+        return j
+
+    def drain(self):
+        """Reduces the partial bucket, waits for every reduction, and starts over at row 0."""
+        if self.i:
+            j = (self.i - 1) % self.ring
+            if self.reduce and j % self.bucket != self.bucket - 1:
+                k = j // self.bucket
+                with self._stream(0):
+                    if self.streams:
+                        for st in self.streams[1:]:
+                            self.streams[0].wait_stream(st)
+                    self.buckets[k][j % self.bucket + 1:].zero_()
+                self._all_reduce(k, 0)
+        for k in range(self.nbuckets):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+        self.i = 0

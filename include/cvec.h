@@ -123,10 +123,10 @@ cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_final
  *                      consecutive sections per wavefront pass, then a pass folds per-vector results:
  *                      parallel over sections, any batch shape;
  *   CVEC_PATH_VSTREAM  one kernel; 16 vectors per wavefront side by side, the section chain followed in LDS:
- *                      parallel over vectors, no index, each byte read once (u32 / f32, blob < 4 GiB).
+ *                      parallel over vectors, no index, each byte read once (u32 / f32, blob < 4 GiB);
  * CVEC_PATH_AUTO (default) picks VSTREAM for sparse batches (at least 16384 vectors, at most 64 sections per
- * vector and 48 bytes per section on average: mostly Null / Const sections), SLOTS otherwise.  Forcing VSTREAM applies wherever the batch is eligible at all
- * (gated and indexed passes, u64 batches and blobs of 4 GiB or more always take SLOTS).  Process-wide;
+ * vector and 48 bytes per section on average: mostly Null / Const sections), SLOTS otherwise.  Forcing
+ * VSTREAM applies wherever the batch is eligible at all (gated and indexed passes, u64 batches and blobs of 4 GiB or more always take SLOTS).  Process-wide;
  * meant for tests and measurements. */
 enum { CVEC_PATH_AUTO = 0, CVEC_PATH_SLOTS = 1, CVEC_PATH_VSTREAM = 2 };
 cvec_status cvec_set_read_path(int32_t path);

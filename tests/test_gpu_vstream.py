@@ -1,7 +1,7 @@
-"""The parity tests that read u32 / f32 batches, run again with the vector-streaming read kernel forced
-(cvec_set_read_path(CVEC_PATH_VSTREAM)): by default small test batches take the section-slot kernel, and
-the two kernels must agree with the oracle on the same inputs: statuses, partial counts, masks and
-decoded values, damaged vectors included."""
+"""The parity tests that read batches, run again with the vector-streaming read kernel forced
+(cvec_set_read_path(CVEC_PATH_VSTREAM)): by default small test batches take the section-slot kernels,
+and both must agree with the oracle on the same inputs: statuses, partial counts, masks and decoded
+values, damaged vectors included."""
 import importlib.util
 import os
 
@@ -22,7 +22,7 @@ cv = P.cv
 
 
 @pytest.fixture(autouse=True)
-def _force_vstream(cv):
+def _force_path(cv):
     from compressed_vec_amd import _native as N
     assert cv.lib().cvec_set_read_path(N.PATH_VSTREAM) == 0
     yield

@@ -69,6 +69,60 @@ def test_sharded_count_allreduce_world2(tmp_path, oracle):
         assert got[0] == want and got[1] == host.n_vectors and got[2] == int(host.byte_off[-1])
 
 
+def _ring_worker(rank, world, port, out_dir, steps):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from compressed_vec_amd.shard import CountBucketRing
+    ring = CountBucketRing(4, "cpu", bucket=8, nbuckets=3)
+    seen = np.zeros((steps, 4), dtype=np.int64)
+    rows = []
+    for rep in range(2):                      # the benchmark runs the ring twice: warm-up steps, then timed steps
+        for i in range(steps):
+            row, _ = ring.begin_step()
+            # the stub step: what a rank's filter pass would leave in its result block
+            row.copy_(torch.tensor([(rank + 1) * (i + 1), rank, i, 1], dtype=torch.int64))
+            rows.append(ring.end_step())
+        ring.drain()
+        assert ring.i == 0 and all(p is None for p in ring.pending)
+    # after drain() the rows of the last min(steps, ring) steps hold global sums
+    for i in range(max(0, steps - ring.ring), steps):
+        seen[i] = ring.rows[rows[steps + i]].numpy()
+    np.save(os.path.join(out_dir, "ring%d.npy" % rank), seen)
+    np.save(os.path.join(out_dir, "coll%d.npy" % rank), np.array([ring.collectives]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_ring_world2_full_buckets_reuse_and_partial_drain(tmp_path):
+    """The benchmark's step / bucket / drain logic under gloo with two ranks and a stub step: 29 steps =
+    3 full buckets, a bucket reused (ring of 24 rows), and a partial bucket of 5 rows reduced by drain()."""
+    world, steps = 2, 29
+    mp.spawn(_ring_worker, args=(world, _free_port(), str(tmp_path), steps), nprocs=world, join=True)
+    for r in range(world):
+        seen = np.load(tmp_path / ("ring%d.npy" % r))
+        # steps 24..28 reused rows 0..4 of the first bucket; drain() zeroed its rows 5..7 (steps 5..7, reduced
+        # long before) so that the partial bucket's reduction does not sum them a second time
+        for i in range(8, steps):
+            assert list(seen[i]) == [3 * (i + 1), 1, 2 * i, 2], (r, i, seen[i])
+        assert not seen[5:8].any()
+        # 29 steps = 3 full buckets + 1 partial, twice
+        assert int(np.load(tmp_path / ("coll%d.npy" % r))[0]) == 8
+
+
+def test_bucket_ring_single_rank_skips_collectives():
+    sys.path.insert(0, ROOT)
+    from compressed_vec_amd.shard import CountBucketRing
+    ring = CountBucketRing(4, "cpu", reduce=False)
+    for i in range(30):
+        row, s = ring.begin_step()
+        row.fill_(i)
+        assert s == 0 and ring.end_step() == i % 24
+    ring.drain()
+    assert ring.collectives == 0 and int(ring.rows[5][0]) == 29
+
+
 def test_partition_balances_bytes_not_vectors():
     sys.path.insert(0, ROOT)
     from compressed_vec_amd.shard import partition_by_bytes
