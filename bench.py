@@ -9,7 +9,10 @@ HBM; for N > 1 every rank owns its own shard of vectors (no data exchange) and t
 are all-reduced over RCCL, eight steps per collective, asynchronously (a collective overlaps the kernels
 of the next steps; every step's count is globally summed before the clock stops).  Workload: 131072 vectors x 2048 f32 per GPU (1 GiB of
 uncompressed values per GPU; at N = 8 this is the 1 Mi vectors x 2048 f32 configuration the metric is quoted on).
-Rank 0 prints one JSON line; `value` is whole-job GB/s counted in uncompressed bytes."""
+Rank 0 prints one JSON line; `value` is whole-job GB/s counted in uncompressed bytes.
+
+`--gpus N` with N > 1 and no rank environment starts its own ranks (python -m torch.distributed.run, one
+per GPU) as child processes before anything touches the GPU, and exits with their code."""
 import argparse
 import ctypes as C
 import json
@@ -37,12 +40,17 @@ def parse_args():
     ap.add_argument("--vectors-per-gpu", type=int, default=VECS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the encode / decode / PCIe side measurements")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the per-configuration table (the reference's four bench vectors at 1 GiB and both "
+                         "data sets of the headline shape: filter / masks / decode / encode)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("BENCH_STREAMS", "1")),
                     help="independent steps in flight: step i runs on stream i %% streams with its own workspace")
     ap.add_argument("--prewarm", type=int, default=300,
                     help="untimed filter passes during set-up, before the warmup steps: the GPU needs a few "
                          "hundred launches to reach its steady clock (0.207 -> 0.195 ms per section kernel)")
+    ap.add_argument("--event-steps", type=int, default=32,
+                    help="timed steps whose kernels are bracketed with HIP events for the roofline figure")
     ap.add_argument("--dist-single", action="store_true",
                     help="take the multi-rank code path (process group, all-reduce) with a single rank; for testing")
     return ap.parse_args()
@@ -68,9 +76,14 @@ def cpu_baseline(dev_batch, n_sample_vectors, seconds, pred):
         if dt >= seconds:
             break
     gbs = passes * elems * 4 / dt / 1e9
-    # the same port on 16 threads (the GPU box's CPU share), vectors split evenly; ctypes releases the GIL
+    # the same port on the threads this process may use (at most 16, the GPU box's CPU share), vectors split
+    # evenly; ctypes releases the GIL
     from concurrent.futures import ThreadPoolExecutor
-    nthr = 16
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    nthr = max(1, min(16, avail, int(os.environ.get("OMP_NUM_THREADS", "16") or 16)))
     cuts = [n * t // nthr for t in range(nthr + 1)]
     parts = [(blob[int(bo[cuts[t]]):int(bo[cuts[t + 1]])], bo[cuts[t]:cuts[t + 1] + 1] - bo[cuts[t]]) for t in range(nthr)]
 
@@ -87,24 +100,64 @@ def cpu_baseline(dev_batch, n_sample_vectors, seconds, pred):
     assert mt_total == total
     mt_gbs = mt_passes * elems * 4 / mt_dt / 1e9
     return {"value": round(gbs, 4), "unit": "GB/s (uncompressed bytes)", "cores": 1, "kind": "port",
-            "value_16_threads": round(mt_gbs, 3),
+            "value_all_threads": round(mt_gbs, 3), "threads": nthr,
+            "host_cpu": host_cpu_description(), "host_logical_cpus": os.cpu_count(), "host_cpus_usable": avail,
             "sample": "first %d of the same %d-element f32 XOR vectors (%d MiB uncompressed), %d passes in %.1f s, "
                       "filter == %.1f + count, oracle/cvec_oracle.c single thread" %
                       (n, VEC_LEN, elems * 4 >> 20, passes, dt, pred)}, total
 
 
+def host_cpu_description():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def launch_ranks(n):
+    """Starts n ranks of this script (one per GPU) through torch.distributed.run and returns their exit code.
+    Called before this process has touched the GPU; the children are fresh processes."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        rc = launch_ranks(args.gpus)
+        if rc:
+            print("bench.py: the %d ranks ended with exit code %d (their messages are above)" % (args.gpus, rc),
+                  file=sys.stderr)
+        sys.exit(rc)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus,
-              file=sys.stderr)
-        sys.exit(2)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < local_world or args.gpus != world:
+        # every rank sees the same numbers and leaves before the rendezvous, so nobody waits for anybody
+        if rank == 0:
+            if have < local_world:
+                print("bench.py: --gpus %d needs %d GPUs on this node, %d visible" % (args.gpus, local_world, have),
+                      file=sys.stderr)
+            else:
+                print("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.dist_single
     if use_dist:
@@ -157,12 +210,6 @@ def main():
     # and the last, partial bucket is reduced before the clock stops, so every step's count is globally
     # summed inside the timed region.  (One collective per step costs ~24 us of GPU time per step: the
     # persistent section kernel leaves the collective's kernel no room until a kernel boundary.)
-    BUCKET, NBUCKETS = 8, 3
-    buckets = [torch.zeros(BUCKET, N.RESULT_WORDS, dtype=torch.int64, device="cuda") for _ in range(NBUCKETS)]
-    results = [buckets[k][j] for k in range(NBUCKETS) for j in range(BUCKET)]
-    RING = BUCKET * NBUCKETS
-    pending = [None] * NBUCKETS
-    state = {"i": 0}
     # --streams S > 1: consecutive steps are independent queries over the same resident batch; step i is
     # enqueued on stream i % S with a workspace of its own, so the short index / finalize kernels of one
     # step run beside the section kernel of another.
@@ -172,39 +219,17 @@ def main():
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     for st in streams[1:]:
         st.wait_stream(streams[0])
+    from compressed_vec_amd.shard import CountBucketRing
+    ring = CountBucketRing(N.RESULT_WORDS, "cuda", bucket=8, nbuckets=3, streams=streams, reduce=use_dist)
 
     def step():
-        i = state["i"]
-        j = i % RING
-        k = j // BUCKET
-        state["i"] += 1
-        if j % BUCKET == 0 and pending[k] is not None:       # first step into a bucket: its last reduction is done
-            for st in streams:
-                with torch.cuda.stream(st):
-                    pending[k].wait()
-            pending[k] = None
-        with torch.cuda.stream(streams[i % nstreams]):
-            views[i % nstreams].filter_count_async(pred, result=results[j])
-            if use_dist and j % BUCKET == BUCKET - 1:
-                for st in streams:                           # the bucket's other steps may be on other streams
-                    if st is not streams[i % nstreams]:
-                        streams[i % nstreams].wait_stream(st)
-                pending[k] = dist.all_reduce(buckets[k], op=dist.ReduceOp.SUM, async_op=True)
-        return j
+        row, si = ring.begin_step()
+        with torch.cuda.stream(streams[si]):
+            views[si].filter_count_async(pred, result=row)
+        return ring.end_step()
 
-    def drain():
-        j = (state["i"] - 1) % RING if state["i"] else 0
-        if use_dist and state["i"] and j % BUCKET != BUCKET - 1:   # the partial bucket of the last steps
-            k = j // BUCKET
-            for st in streams[1:]:
-                streams[0].wait_stream(st)
-            buckets[k][j % BUCKET + 1:].zero_()
-            pending[k] = dist.all_reduce(buckets[k], op=dist.ReduceOp.SUM, async_op=True)
-        for k in range(NBUCKETS):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-        state["i"] = 0                      # the next loop starts a fresh bucket
+    drain = ring.drain
+    results = ring.rows
 
     for _ in range(args.prewarm):          # set-up: clocks to steady state (no collective, not a step)
         batch.filter_count_async(pred, result=results[0])
@@ -216,7 +241,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    N.check(lib.cvec_timing_begin(min(args.steps, 4096)))   # per-kernel events for the first 4096 steps at most
+    # per-kernel HIP events on the launch stream for the first steps of the timed region only: six event
+    # records cost ~0.018 ms per step, which would be charged to every step's wall time otherwise
+    N.check(lib.cvec_timing_begin(min(args.steps, args.event_steps)))
     t0 = time.perf_counter()
     last = 0
     for _ in range(args.steps):
@@ -282,7 +309,7 @@ def main():
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "algorithmic_bytes_per_launch": raw_bytes,
-                           "avg_launch_ms": round(k_sections_ms, 4),
+                           "avg_launch_ms": round(k_sections_ms, 4), "launches_timed": nrec.value,
                            "other_kernels_ms": {"k_index": round(ms[0].value / max(nrec.value, 1), 4),
                                                 "k_finalize": round(ms[2].value / max(nrec.value, 1), 4)}}
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
@@ -291,6 +318,10 @@ def main():
         if not args.no_extra and world == 1:
             out["extra"] = side_measurements(torch, cv, batch, values, elem_off, raw_bytes)
             out["extra"]["first_encode_call_s"] = round(t_first_encode, 4)
+            if not args.no_configs:
+                del values, batch
+                torch.cuda.empty_cache()
+                out["extra"]["configs"] = config_table(torch, cv, N)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
@@ -372,6 +403,88 @@ def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
     ex["host_inclusive_note"] = ("cvec_*_batch on page-locked host arrays: chunked H2D + kernels + D2H pipelined over three "
                                  "streams, uncompressed bytes / wall")
     return ex
+
+
+def config_table(torch, cv, N):
+    """The reference's `cargo bench vector` configurations (benches/bench.rs:131-170) as batches of 1 GiB
+    of uncompressed values, and both data sets at the headline shape: for each, encode_all, decode through
+    AddConst -> VecSink, filter + count and filter with per-section masks, in GB/s of uncompressed bytes,
+    with the per-kernel times of the filter pass and the fraction of the HBM peak its dominant kernel
+    reaches (uncompressed bytes / kernel time / 8 TB/s, the headline's formula)."""
+    from compressed_vec_amd import synth
+    lib = cv.lib()
+    rows = []
+
+    def kernel_ms(fn, iters):
+        N.check(lib.cvec_timing_begin(iters))
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        ms = [C.c_float(0), C.c_float(0), C.c_float(0)]
+        nrec = C.c_int32(0)
+        N.check(lib.cvec_timing_end(C.byref(ms[0]), C.byref(ms[1]), C.byref(ms[2]), C.byref(nrec)))
+        return [m.value / max(nrec.value, 1) for m in ms]
+
+    def one(name, tname, kind, nvec, length, pred, add_const):
+        chunks = []
+        for c0 in range(0, nvec, 4096):
+            cn = min(4096, nvec - c0)
+            if kind == "f32_splitmix":
+                chunks.append(synth.splitmix_f32_torch(cn, length, v_first=c0)[0])
+            else:
+                chunks.append(synth.batch_values_torch("u32_dense" if kind == "u32_sparse" else kind, cn, length,
+                                                       v_first=c0)[0])
+        vals = torch.cat(chunks)
+        del chunks
+        if pred is None:
+            pred = float(vals[12345].item())        # a value that occurs
+        if kind == "u32_sparse":
+            # benches/bench.rs:160-170: two runs of 50 values in a vector of nulls (zeros)
+            keep = torch.zeros(length, dtype=torch.bool, device="cuda")
+            keep[2475:2525] = True
+            keep[7475:7525] = True
+            vals = torch.where(keep.repeat(nvec), vals, torch.zeros_like(vals))
+        eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * length
+        raw = vals.numel() * vals.element_size()
+        batch = cv.encode_device(tname, vals, eo)
+        t_enc = _time_gpu(torch, lambda: cv.encode_device(tname, vals, eo), 5)
+        out = torch.empty(batch.n_sections * 256, dtype=vals.dtype, device="cuda")
+        masks = torch.empty(batch.n_sections * 32, dtype=torch.uint8, device="cuda")
+        res = batch.result_buffer()
+        p = cv.make_pred(batch.etype, pred)
+        want = int((vals == pred).sum().item())
+        t_dec = _time_gpu(torch, lambda: batch.decode_async(out, add_const=add_const), 10)
+        t_fil = _time_gpu(torch, lambda: batch.filter_count_async(p, result=res), 30)
+        got = int(res[0].item())
+        t_msk = _time_gpu(torch, lambda: batch.filter_count_async(p, result=res, masks=masks), 10)
+        k_fil = kernel_ms(lambda: batch.filter_count_async(p, result=res), 20)
+        k_dec = kernel_ms(lambda: batch.decode_async(out, add_const=add_const), 10)
+        dom = max(k_fil)
+        rows.append({"config": name, "vectors": nvec, "vector_len": length, "raw_MiB": raw >> 20,
+                     "compressed_B_per_elem": round(batch.n_bytes / vals.numel(), 3),
+                     "encode_GBs": round(raw / t_enc / 1e9, 1), "decode_addconst_GBs": round(raw / t_dec / 1e9, 1),
+                     "filter_GBs": round(raw / t_fil / 1e9, 1), "filter_masks_GBs": round(raw / t_msk / 1e9, 1),
+                     "filter_ms": round(t_fil * 1e3, 4),
+                     "filter_kernels_ms": {"index_or_memset": round(k_fil[0], 4), "sections_or_vstream": round(k_fil[1], 4),
+                                           "finalize": round(k_fil[2], 4)},
+                     "decode_kernels_ms": {"index_or_memset": round(k_dec[0], 4), "sections_or_vstream": round(k_dec[1], 4),
+                                           "finalize": round(k_dec[2], 4)},
+                     "filter_roofline_frac": round(raw / (dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dom > 0 else None,
+                     # decode moves the compressed bytes in and the uncompressed bytes out
+                     "decode_roofline_frac": round((raw + batch.n_bytes) / (max(k_dec) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                     if max(k_dec) > 0 else None,
+                     "filter_count_equals_direct_count": bool(got == want)})
+        del vals, batch, out, masks
+        torch.cuda.empty_cache()
+
+    n = 26214                                       # x 10000 x 4 B = 1 GiB
+    one("cfg1 u32 dense (bench.rs:131-141)", "u32", "u32_dense", n, 10000, 3, 7)
+    one("cfg2 u32 sparse (bench.rs:160-170)", "u32", "u32_sparse", n, 10000, 15, 7)
+    one("cfg3 f32 xor (bench.rs:143-150)", "f32", "f32_xor", n, 10000, 3.0, 2.5)
+    one("cfg4 u64 delta (bench.rs:152-158)", "u64", "u64_delta", n // 2, 10000, 100003, 5)
+    one("cfg5 f32 xor sinusoid, 2048-element vectors", "f32", "f32_xor", VECS_PER_GPU, VEC_LEN, PRED, 2.5)
+    one("cfg5 f32 xor splitmix, 2048-element vectors", "f32", "f32_splitmix", VECS_PER_GPU, VEC_LEN, None, 2.5)
+    return rows
 
 
 if __name__ == "__main__":

@@ -76,6 +76,9 @@ SIGNATURES = {
                                       C.c_void_p]),
     "cvec_filter_count_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_filter_set_workspace_bytes": (C.c_size_t, [C.c_uint64, C.c_uint64]),
+    "cvec_filter_count_set_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "cvec_filter_count_static_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvec_filter_count_gated_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.c_void_p, C.c_void_p,

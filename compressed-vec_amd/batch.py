@@ -185,10 +185,11 @@ class DeviceBatch:
         return EncodedBatch(self.etype, blob, off)
 
     # -- scratch owned by the batch so that repeated queries allocate nothing ------------------------
-    def workspace(self):
-        if self._ws is None:
-            nbytes = N.lib().cvec_workspace_bytes(self.n_vectors, self.n_sections)
+    def workspace(self, min_bytes=0):
+        nbytes = max(N.lib().cvec_workspace_bytes(self.n_vectors, self.n_sections), min_bytes)
+        if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._index_valid = False
         return self._ws
 
     def layout_signature(self):
@@ -238,9 +239,20 @@ class DeviceBatch:
         """Enqueues decode+filter+count on the current stream; returns the device result tensor
         (int64[4]: total, failed vectors, max status, reserved).  `gate`: masks of an earlier pass over
         a batch with the same section layout; sections whose gate mask is empty are not decoded."""
+        res = result if result is not None else self.result_buffer()
+        if isinstance(pred, (list, tuple, np.ndarray)) and len(pred) > N.MAX_PRED_VALUES:
+            # OneOf over a large set (the reference's set is a Vec, src/filter.rs:143-160): one pass per 16 values
+            if gate is not None:
+                raise N.CodingError(N.ERR_BAD_ARGUMENT, "a gated pass takes at most %d values" % N.MAX_PRED_VALUES)
+            vals = (C.c_uint64 * len(pred))(*[_bits(self.etype, v) for v in pred])
+            ws = self.workspace(N.lib().cvec_filter_set_workspace_bytes(self.n_vectors, self.n_sections))
+            with torch.cuda.device(self.device):
+                N.check(N.lib().cvec_filter_count_set_dev(C.byref(self.view), vals, len(pred), _ptr(res), _ptr(per_vector),
+                                                          _ptr(status), _ptr(masks), _ptr(ws), ws.numel(), _stream_ptr()))
+            self._index_valid = False
+            return res
         p = pred if isinstance(pred, N.Pred) else make_pred(self.etype, pred)
         ws = self.workspace()
-        res = result if result is not None else self.result_buffer()
         if self._keep_index and not self._index_valid:
             self.build_index()                  # an unindexed pass used the workspace since: walk the headers again
         with torch.cuda.device(self.device):

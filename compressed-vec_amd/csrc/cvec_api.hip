@@ -32,6 +32,9 @@ hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uin
                                  const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
                                  hipStream_t stream);
 void set_read_path(int path);
+hipError_t launch_merge_filter_pass(uint64_t n_vectors, uint64_t n_sections, const uint64_t *tmp_result,
+                                    const uint64_t *tmp_per, const uint8_t *tmp_masks, uint64_t *result, uint64_t *per,
+                                    uint8_t *masks, hipStream_t stream);
 hipError_t launch_multi_and(const MaskColumns &cols, uint64_t n_rows, uint64_t n_slots0, uint8_t *out_masks,
                             uint16_t *popc, uint8_t *ended, uint64_t *per_row, uint32_t *row_sections,
                             uint64_t *result, hipStream_t stream);
@@ -569,6 +572,77 @@ static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, 
     hipError_t e = launch_read(0, phase, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, d_per_vector, d_status,
                                d_masks, nullptr, d_gate, w.tag, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_filter_count_dev");
+    return CVEC_OK;
+}
+
+// Workspace of the large-set filter: the read workspace, then a result block, per-vector counts and masks for the
+// passes after the first.
+struct SetWs {
+    size_t read_bytes, result_off, per_off, masks_off, total;
+};
+static SetWs carve_set_ws(uint64_t n_vectors, uint64_t n_sections) {
+    SetWs w;
+    w.read_bytes = align_up(cvec_workspace_bytes(n_vectors, n_sections), 256);
+    w.result_off = w.read_bytes;
+    w.per_off = w.result_off + 256;
+    w.masks_off = w.per_off + align_up((n_vectors + 1) * 8, 256);
+    w.total = w.masks_off + align_up((n_sections + 1) * 32, 256);
+    return w;
+}
+
+size_t cvec_filter_set_workspace_bytes(uint64_t n_vectors, uint64_t n_sections) {
+    return carve_set_ws(n_vectors, n_sections).total;
+}
+
+cvec_status cvec_filter_count_set_dev(const cvec_dbatch_view *batch, const uint64_t *values, uint32_t n_values,
+                                      uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                      void *d_workspace, size_t workspace_bytes, void *stream) {
+    cvec_status st = check_view(batch);
+    if (st) return st;
+    if (!values || n_values == 0 || !d_result || !d_workspace) return CVEC_ERR_BAD_ARGUMENT;
+    const SetWs w = carve_set_ws(batch->n_vectors, batch->n_sections);
+    if (w.total > workspace_bytes) return CVEC_ERR_WORKSPACE;
+    // Distinct members only (a value listed twice, or +0.0 beside -0.0, must not count its elements twice once the
+    // set is split into passes); a NaN equals nothing (IEEE ==) and is dropped unless it is all there is.
+    std::vector<uint64_t> set;
+    set.reserve(n_values);
+    const bool f32 = batch->etype == CVEC_F32;
+    auto key = [&](uint64_t v) -> uint64_t {
+        if (batch->etype != CVEC_U64) v &= 0xffffffffull;
+        if (f32 && (v & 0x7fffffffull) == 0) v = 0;
+        return v;
+    };
+    for (uint32_t i = 0; i < n_values; i++) {
+        const uint64_t k = key(values[i]);
+        if (f32 && (k & 0x7fffffffull) > 0x7f800000ull) continue;
+        bool seen = false;
+        for (uint64_t s : set) seen |= key(s) == k;
+        if (!seen) set.push_back(batch->etype != CVEC_U64 ? (values[i] & 0xffffffffull) : values[i]);
+    }
+    if (set.empty()) set.push_back(values[0] & 0xffffffffull); // only NaNs: one pass that matches nothing
+    uint8_t *base = (uint8_t *)d_workspace;
+    uint64_t *tmp_result = (uint64_t *)(base + w.result_off);
+    uint64_t *tmp_per = (uint64_t *)(base + w.per_off);
+    uint8_t *tmp_masks = base + w.masks_off;
+    for (size_t at = 0, pass = 0; at < set.size(); at += CVEC_MAX_PRED_VALUES, pass++) {
+        cvec_pred p;
+        memset(&p, 0, sizeof(p));
+        p.kind = CVEC_PRED_ONEOF;
+        p.count = (uint32_t)(set.size() - at < CVEC_MAX_PRED_VALUES ? set.size() - at : CVEC_MAX_PRED_VALUES);
+        for (uint32_t i = 0; i < p.count; i++) p.values[i] = set[at + i];
+        if (pass == 0) {
+            st = filter_count_phase(READ_ALL, batch, &p, nullptr, d_result, d_per_vector, d_status, d_masks, d_workspace,
+                                    w.read_bytes, stream);
+            if (st) return st;
+            continue;
+        }
+        st = filter_count_phase(READ_ALL, batch, &p, nullptr, tmp_result, d_per_vector ? tmp_per : nullptr, nullptr,
+                                d_masks ? tmp_masks : nullptr, d_workspace, w.read_bytes, stream);
+        if (st) return st;
+        hipError_t e = launch_merge_filter_pass(batch->n_vectors, batch->n_sections, tmp_result, tmp_per, tmp_masks, d_result,
+                                                d_per_vector, d_masks, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "cvec_filter_count_set_dev");
+    }
     return CVEC_OK;
 }
 

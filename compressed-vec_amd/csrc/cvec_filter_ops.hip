@@ -163,7 +163,40 @@ __global__ void k_pos_off(const uint64_t *__restrict__ sec_base, uint64_t n, con
     if (v <= n) pos_off[v] = scan[sec_base[v]];
 }
 
+// k_merge_filter_pass: adds the outcome of one more filter pass (a further bucket of a large OneOf set; the buckets
+// hold distinct values, so an element matches in at most one of them) into the outputs of the passes before it:
+// per-vector counts and the total add up, per-section masks are OR-ed (OneOfIF::filter_bitmask ORs the masks of the
+// set's members, src/filter.rs:167-174).  Statuses are the same in every pass and stay as the first pass left them.
+__global__ __launch_bounds__(256) void k_merge_filter_pass(uint64_t n_vectors, uint64_t n_mask_words,
+                                                           const uint64_t *__restrict__ tmp_result,
+                                                           const uint64_t *__restrict__ tmp_per,
+                                                           const uint64_t *__restrict__ tmp_masks,
+                                                           uint64_t *__restrict__ result, uint64_t *__restrict__ per,
+                                                           uint64_t *__restrict__ masks) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) result[0] += tmp_result[0];
+    if (per != nullptr && i < n_vectors) per[i] += tmp_per[i];
+    if (masks != nullptr) {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t w = i; w < n_mask_words; w += stride) masks[w] |= tmp_masks[w];
+    }
+}
+
 // ---- launchers ----------------------------------------------------------------------------------------
+hipError_t launch_merge_filter_pass(uint64_t n_vectors, uint64_t n_sections, const uint64_t *tmp_result,
+                                    const uint64_t *tmp_per, const uint8_t *tmp_masks, uint64_t *result, uint64_t *per,
+                                    uint8_t *masks, hipStream_t stream) {
+    const uint64_t words = masks ? n_sections * 4 : 0;
+    uint64_t items = n_vectors > words ? n_vectors : words;
+    if (items == 0) items = 1;
+    uint64_t blocks = (items + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks * 256 < n_vectors) blocks = (n_vectors + 255) / 256;
+    k_merge_filter_pass<<<(uint32_t)blocks, 256, 0, stream>>>(n_vectors, words, tmp_result, tmp_per, (const uint64_t *)tmp_masks,
+                                                              result, per, (uint64_t *)masks);
+    return hipGetLastError();
+}
+
 hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uint64_t *desc, const uint32_t *sec_res,
                                  const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
                                  hipStream_t stream) {

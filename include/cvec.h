@@ -157,6 +157,17 @@ cvec_status cvec_filter_count_dev(const cvec_dbatch_view *batch, const cvec_pred
                                   uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
                                   void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* OneOfSink over a set of any size: the reference's MembershipPredicate holds a Vec of values
+ * (src/filter.rs:143-160) and OneOfIF ORs one comparison per member (:162-175).  values: n_values raw
+ * element bits in HOST memory (duplicates, and -0.0 beside +0.0, count once; NaNs equal nothing).  Sets of
+ * up to CVEC_MAX_PRED_VALUES distinct values take one pass, like cvec_filter_count_dev; larger sets take
+ * one pass per CVEC_MAX_PRED_VALUES values, with counts added and masks OR-ed on the device.  Outputs as
+ * for cvec_filter_count_dev; the workspace is cvec_filter_set_workspace_bytes() bytes. */
+size_t cvec_filter_set_workspace_bytes(uint64_t n_vectors, uint64_t n_sections);
+cvec_status cvec_filter_count_set_dev(const cvec_dbatch_view *batch, const uint64_t *values, uint32_t n_values,
+                                      uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                      void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* cvec_filter_count_dev without a workspace argument and without any allocation: the scratch is a
  * static device array inside the library (CVEC_STATIC_SCRATCH_BYTES per GPU, held until the process
  * ends).  No counterpart in the reference; it exists for callers that cannot allocate or size device

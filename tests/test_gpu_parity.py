@@ -174,6 +174,42 @@ def test_filter_count_and_masks_vs_oracle(cv, oracle, tname):
             assert np.array_equal(gm, wm), (p, v)
 
 
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_oneof_sets_larger_than_one_pass_vs_oracle(cv, oracle, tname):
+    """OneOfSink over sets of 17..50 values (the reference's set is a Vec, src/filter.rs:143-175): the library
+    splits them into passes of 16 and merges counts and masks on the device.  Duplicates, zero (and for f32
+    both zeros and a NaN) in the set, and a damaged vector whose partial count must add up the same way."""
+    rng = np.random.default_rng(900 + ET[tname])
+    vals, eo = _random_vectors(rng, tname, 120)
+    blob, bo = oracle.batch_encode(ET[tname], vals, eo)
+    blob = blob.copy()
+    v_bad = 17
+    mid = (int(bo[v_bad]) + int(bo[v_bad + 1])) // 2
+    blob[mid:int(bo[v_bad + 1])] = 0xEE                      # cut vector 17 short in the middle of a section
+    dev = cv.EncodedBatch(tname, blob, bo).to_device()
+    distinct = np.unique(vals[vals != 0])
+    rng.shuffle(distinct)
+    sets = [list(distinct[:17]), list(distinct[:33]) + [0], list(distinct[:24]) * 2 + [distinct[30]]]
+    if tname == "f32":
+        sets.append(list(distinct[:20]) + [0.0, -0.0, float("nan")] + list(distinct[20:40]))
+    else:
+        sets.append(list(distinct[:50]))
+    for p in sets:
+        p = [x.item() if hasattr(x, "item") else x for x in p]
+        total, per, st, masks = dev.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+        wtotal, wper, wst, rc = oracle.batch_filter_count(ET[tname], blob, bo, p)
+        assert total == wtotal and np.array_equal(per, wper) and np.array_equal(st, wst), len(p)
+        assert st[v_bad] != 0
+        sb = dev.d_sec_base.cpu().numpy()
+        valid, _pf = dev.valid_sections()
+        for v in list(range(0, eo.size - 1, 13)) + [v_bad]:
+            _, wm = oracle.filter_count(ET[tname], blob[int(bo[v]):int(bo[v + 1])], p, return_masks=True)
+            wm = np.asarray(wm, dtype=np.uint8).reshape(-1)
+            gm = masks[32 * int(sb[v]):32 * (int(sb[v]) + int(valid[v]))]
+            assert np.array_equal(gm, wm[:gm.size]), (len(p), v)
+        assert dev.filter_count(p, return_status=True)[0] == wtotal     # count only: no per-vector / mask merge
+
+
 def test_reference_test_cases_through_the_api_mirror(cv):
     """The reference's own vector/filter tests, phrased with the same API names."""
     # src/vector.rs:669-684

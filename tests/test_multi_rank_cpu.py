@@ -123,6 +123,20 @@ def test_bucket_ring_single_rank_skips_collectives():
     assert ring.collectives == 0 and int(ring.rows[5][0]) == 29
 
 
+def test_bench_starts_its_own_ranks_and_says_what_it_needs():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns two ranks before touching the GPU; on
+    a machine with fewer than two GPUs the ranks leave before the rendezvous with a clear message."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this machine has the GPUs; the message under test is for one that has not")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 GPUs on this node" in r.stderr
+    assert "the 2 ranks ended with exit code" in r.stderr
+
+
 def test_partition_balances_bytes_not_vectors():
     sys.path.insert(0, ROOT)
     from compressed_vec_amd.shard import partition_by_bytes
