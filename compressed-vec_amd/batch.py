@@ -221,6 +221,25 @@ class DeviceBatch:
                                                     _stream_ptr()))
         return valid.cpu().numpy()[:self.n_vectors].view(np.uint32), pf.cpu().numpy()[:self.n_vectors].astype(bool)
 
+    def error_details(self, status):
+        """After a filter or decode pass that returned per-vector statuses: an (n_vectors, 2) uint64 array,
+        [section index at which the vector's iteration stopped (2**64-1: its header), payload of the reference's
+        CodingError (BadOffset offset, InvalidSectionType byte, WrongVectorType byte; otherwise the byte offset of
+        that section in the vector)]; zeros for vectors that did not fail."""
+        ws = self.workspace()
+        n = max(self.n_vectors, 1)
+        st = torch.as_tensor(np.ascontiguousarray(status, dtype=np.int32), device=self.device) \
+            if not isinstance(status, torch.Tensor) else status
+        valid = torch.empty(n, dtype=torch.int32, device=self.device)
+        pf = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        detail = torch.zeros(2 * n, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().cvec_valid_sections_dev(C.byref(self.view), _ptr(ws), ws.numel(), _ptr(valid), _ptr(pf),
+                                                    _stream_ptr()))
+            N.check(N.lib().cvec_error_detail_dev(C.byref(self.view), _ptr(st), _ptr(valid), _ptr(pf), _ptr(detail),
+                                                  _stream_ptr()))
+        return detail.cpu().numpy().view(np.uint64).reshape(-1, 2)[:self.n_vectors]
+
     # -- operations -------------------------------------------------------------------------------------
     def build_index(self):
         """Walks the section headers of every vector once (what each read operation otherwise does as

@@ -32,6 +32,8 @@ hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uin
                                  const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
                                  hipStream_t stream);
 void set_read_path(int path);
+hipError_t launch_error_detail(int etype, const uint8_t *bytes, const uint64_t *byte_off, uint64_t n, const int32_t *status,
+                               const uint32_t *valid, const uint8_t *parse_failed, uint64_t *detail, hipStream_t stream);
 hipError_t launch_merge_filter_pass(uint64_t n_vectors, uint64_t n_sections, const uint64_t *tmp_result,
                                     const uint64_t *tmp_per, const uint8_t *tmp_masks, uint64_t *result, uint64_t *per,
                                     uint8_t *masks, hipStream_t stream);
@@ -697,6 +699,17 @@ cvec_status cvec_valid_sections_dev(const cvec_dbatch_view *batch, const void *d
 }
 
 // multi workspace: popc[n] u16 | ended[n] u8
+cvec_status cvec_error_detail_dev(const cvec_dbatch_view *batch, const int32_t *d_status, const uint32_t *d_valid,
+                                  const uint8_t *d_parse_failed, uint64_t *d_detail, void *stream) {
+    cvec_status st = check_view(batch);
+    if (st) return st;
+    if (batch->n_vectors && (!d_status || !d_valid || !d_parse_failed || !d_detail)) return CVEC_ERR_BAD_ARGUMENT;
+    hipError_t e = launch_error_detail(batch->etype, batch->d_bytes, batch->d_byte_off, batch->n_vectors, d_status, d_valid,
+                                       d_parse_failed, d_detail, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "cvec_error_detail_dev");
+    return CVEC_OK;
+}
+
 size_t cvec_multi_workspace_bytes(uint64_t n_sections_col0) {
     return align_up((n_sections_col0 + 1) * 2, 256) + align_up(n_sections_col0 + 1, 256);
 }

@@ -50,6 +50,76 @@ __global__ __launch_bounds__(256) void k_valid_sections(const uint64_t *__restri
     if (parse_failed) parse_failed[v] = (!decode_error && vstatus[v] != 0) ? 1 : 0;
 }
 
+// k_error_detail: for every vector whose status is not OK, the two words the reference's CodingError would carry
+// (src/error.rs:2-11) plus where the iteration stopped: detail[2v] = index of the section at which it stopped (all
+// ones: the vector header, VectorReader::try_new, src/vector.rs:404-414), detail[2v+1] = the offset of BadOffset, the
+// type byte of InvalidSectionType, the subtype byte of WrongVectorType, and for every other code the byte offset of
+// that section inside the vector (0 for the header).  One lane per vector; only failed vectors walk their headers
+// again, up to the section the pass before stopped at (valid[v], from k_valid_sections).
+template <int W>
+__global__ __launch_bounds__(256) void k_error_detail(const uint8_t *__restrict__ bytes,
+                                                      const uint64_t *__restrict__ byte_off, uint64_t n, int etype,
+                                                      const int32_t *__restrict__ status,
+                                                      const uint32_t *__restrict__ valid,
+                                                      const uint8_t *__restrict__ parse_failed,
+                                                      uint64_t *__restrict__ detail) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint64_t d0 = 0, d1 = 0;
+    if (status[v] != 0) {
+        const uint8_t *p = bytes + byte_off[v];
+        const uint64_t L = byte_off[v + 1] - byte_off[v];
+        bool header = true;
+        if (L == 0 || L < 4) d1 = 0;
+        else if (L <= 5) d1 = 5;
+        else {
+            const uint64_t from_header = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24);
+            if (L < from_header + 4) d1 = 0;
+            else if (p[5] != (uint8_t)etype) d1 = p[5];
+            else if (L < (uint64_t)HEADER_BYTES) d1 = 0;
+            else header = false;
+        }
+        if (header) {
+            d0 = ~0ull;
+        } else {
+            uint64_t pos = HEADER_BYTES;
+            uint32_t k = 0;
+            const uint32_t nv = valid[v];
+            while (k < nv && pos < L) { // these headers parsed in the pass before
+                const uint32_t b0 = p[pos];
+                uint64_t nb = 1;
+                if (b0 == K_CONST) nb = 1 + W;
+                else if (b0 != K_NULL) {
+                    if (L - pos < 3) break;
+                    const uint32_t n16 = (uint32_t)p[pos + 1] | ((uint32_t)p[pos + 2] << 8);
+                    nb = b0 == K_NP ? (uint64_t)n16 + 3 : (b0 == K_DELTA ? (uint64_t)n16 + DELTA_HDR : n16);
+                    if (nb < 3) break;
+                }
+                pos += nb; k++;
+            }
+            d0 = k;
+            d1 = pos;
+            if (parse_failed[v] && pos < L) {
+                const uint32_t b0 = p[pos];
+                const bool octets = b0 == K_NP || b0 == K_DELTA || b0 == K_XOR;
+                if (octets && L - pos <= 1) d1 = 1;                                   // BadOffset(1): the u16 behind the type byte
+                else if (!octets && b0 != K_NULL && b0 != K_CONST) d1 = b0;           // InvalidSectionType(byte)
+            }
+        }
+    }
+    detail[2 * v] = d0;
+    detail[2 * v + 1] = d1;
+}
+
+hipError_t launch_error_detail(int etype, const uint8_t *bytes, const uint64_t *byte_off, uint64_t n, const int32_t *status,
+                               const uint32_t *valid, const uint8_t *parse_failed, uint64_t *detail, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    if (etype == CVEC_U64) k_error_detail<8><<<blocks, 256, 0, stream>>>(bytes, byte_off, n, etype, status, valid, parse_failed, detail);
+    else k_error_detail<4><<<blocks, 256, 0, stream>>>(bytes, byte_off, n, etype, status, valid, parse_failed, detail);
+    return hipGetLastError();
+}
+
 struct MaskColumns {
     const uint8_t *masks[CVEC_MAX_PRED_VALUES];
     const uint64_t *sec_base[CVEC_MAX_PRED_VALUES];

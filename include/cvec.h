@@ -231,6 +231,18 @@ cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain
 cvec_status cvec_valid_sections_dev(const cvec_dbatch_view *batch, const void *d_workspace, size_t workspace_bytes,
                                     uint32_t *d_valid, uint8_t *d_parse_failed, void *stream);
 
+/* The payload of the reference's CodingError (src/error.rs:2-11) for every failed vector of the pass
+ * before, and where its iteration stopped.  d_status: the statuses that pass wrote; d_valid /
+ * d_parse_failed: what cvec_valid_sections_dev made of its workspace.  d_detail: 2 * n_vectors u64;
+ * for vector v, d_detail[2v] = index of the section at which the iteration stopped (all ones: the vector
+ * header, VectorReader::try_new, src/vector.rs:404-414) and d_detail[2v+1] = the offset of BadOffset(usize),
+ * the type byte of InvalidSectionType(u8), the subtype byte of WrongVectorType(u8); for every other code
+ * the byte offset, inside the vector, of the section where it stopped (0 for the header).  Both words
+ * are 0 for a vector whose status is CVEC_OK.  (InvalidFormat and ScrollErr carry strings in the
+ * reference; the section index and offset stand in for them.) */
+cvec_status cvec_error_detail_dev(const cvec_dbatch_view *batch, const int32_t *d_status, const uint32_t *d_valid,
+                                  const uint8_t *d_parse_failed, uint64_t *d_detail, void *stream);
+
 /* One filtered vector column: the masks cvec_filter_count_dev wrote for a batch, that batch's
  * sec_base and the valid-section counts from cvec_valid_sections_dev. */
 #define CVEC_MAX_COLUMNS 16

@@ -76,6 +76,7 @@ def lib():
             "ocv_encode_all": (C.c_int64, [C.c_int, vp, C.c_size_t, vp, C.c_size_t]),
             "ocv_max_encoded_size": (C.c_size_t, [C.c_int, C.c_size_t]),
             "ocv_reader_check": (C.c_int, [C.c_int, vp, C.c_size_t, u64p]),
+            "ocv_error_detail": (C.c_int, [C.c_int, vp, C.c_size_t, u64p]),
             "ocv_reader_num_elements": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]),
             "ocv_reader_sections": (C.c_int, [C.c_int, vp, C.c_size_t, szp, vp, C.c_size_t]),
             "ocv_decode_to_vec": (C.c_int, [C.c_int, vp, C.c_size_t, C.c_int, vp, vp, C.c_size_t, szp]),
@@ -327,6 +328,14 @@ def reader_check(etype, buf):
     b = _bytes_arr(buf)
     d = C.c_uint64(0)
     return lib().ocv_reader_check(etype, _ptr(b), b.size, C.byref(d)), d.value
+
+
+def error_detail(etype, buf):
+    """(status, section index at which the iteration stops or 2**64-1 for the vector header, payload)."""
+    b = _bytes_arr(buf)
+    d = (C.c_uint64 * 2)(0, 0)
+    rc = lib().ocv_error_detail(etype, _ptr(b), b.size, d)
+    return rc, int(d[0]), int(d[1])
 
 
 def reader_num_elements(buf):

@@ -893,6 +893,35 @@ int ocv_reader_sections(int etype, const uint8_t *bytes, size_t len, size_t *cou
     return OCV_OK;
 }
 
+/* Where and why the iteration over a vector stops, in two words: detail[0] = index of the section at which it
+ * stops (all ones: the vector header itself, VectorReader::try_new), detail[1] = the payload the reference's
+ * CodingError carries (error.rs:2-11): the offset of BadOffset, the type byte of InvalidSectionType, the subtype
+ * byte of WrongVectorType; for every other code the byte offset, inside the vector, of the section where it
+ * stops (0 for the header).  Returns the code, OCV_OK (detail 0, 0) for a vector that iterates to its end. */
+int ocv_error_detail(int etype, const uint8_t *bytes, size_t len, uint64_t detail[2]) {
+    uint64_t d = 0;
+    detail[0] = detail[1] = 0;
+    int rc = ocv_reader_check(etype, bytes, len, &d);
+    if (rc) { detail[0] = ~0ull; detail[1] = d; return rc; }
+    s256_sink s;
+    s256_init(&s, elem_width(etype));
+    size_t pos = HEADER_BYTES, k = 0;
+    while (pos < len) {
+        int kind; size_t nb;
+        rc = ocv_section_parse(etype, bytes + pos, len - pos, &kind, &nb);
+        if (rc) {
+            detail[0] = k;
+            detail[1] = rc == OCV_BAD_OFFSET ? 1 : rc == OCV_INVALID_SECTION_TYPE ? bytes[pos] : pos;
+            return rc;
+        }
+        s.s.reset(&s.s);
+        rc = section_decode_to(etype, kind, bytes + pos, nb, len - pos - nb, &s.s);
+        if (rc) { detail[0] = k; detail[1] = pos; return rc; }
+        pos += nb; k++;
+    }
+    return OCV_OK;
+}
+
 static int decode_vector_to(int etype, const uint8_t *bytes, size_t len, sink *out) {  /* vector.rs:458-464 */
     int rc = ocv_reader_check(etype, bytes, len, NULL);
     if (rc) return rc;

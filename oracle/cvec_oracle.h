@@ -123,6 +123,7 @@ size_t ocv_max_encoded_size(int etype, size_t n);
 
 /* VectorReader::try_new (vector.rs:404-414).  detail receives the WrongVectorType byte. */
 int ocv_reader_check(int etype, const uint8_t *bytes, size_t len, uint64_t *detail);
+int ocv_error_detail(int etype, const uint8_t *bytes, size_t len, uint64_t detail[2]);
 int ocv_reader_num_elements(const uint8_t *bytes, size_t len, uint32_t *n, uint16_t *null_sections);
 /* sect_iter().count() and per-section kinds (up to max_kinds) — vector.rs:442, section.rs:864-876. */
 int ocv_reader_sections(int etype, const uint8_t *bytes, size_t len, size_t *count,

@@ -346,8 +346,18 @@ def test_malformed_vectors_report_status_and_partial_counts(cv, oracle):
     assert np.array_equal(per, wper)
     assert total == wtotal
     assert st[0] == 0 and st[-1] == 0 and st[1] == 7 and st[2] == 4 and st[3] == 5 and st[6] == 5
+    # the payloads of the reference's CodingError (src/error.rs:2-11) and where each iteration stopped
+    det = dev.error_details(st)
+    for v, vec in enumerate(vecs):
+        rc, k, payload = oracle.error_detail(oracle.U32, vec)
+        assert rc == st[v] and (int(det[v, 0]), int(det[v, 1])) == (k, payload), v
+    assert tuple(det[1]) == (2**64 - 1, 0x10)         # WrongVectorType(0x10), found in the vector header
+    assert tuple(det[2]) == (1, 9)                    # InvalidSectionType(9) at the second section
+    assert int(det[3, 0]) == 1 and int(det[3, 1]) == 16 + nb      # second section fails to decode: its offset
+    assert not det[0].any() and not det[-1].any()
     _, _, dst = dev.decode(return_status=True)
     assert list(dst) == list(wst)
+    assert np.array_equal(dev.error_details(dst), det)
 
 
 def test_damaged_element_count_is_bounded_by_the_bytes(cv, oracle):
@@ -390,7 +400,7 @@ def test_randomly_damaged_batches_vs_oracle(cv, oracle):
     for seed in range(5000, 5120):
         for tname in ("u32", "u64", "f32"):
             assert fz.one_round(seed, tname, [0, 1, 3, 12][seed % 4]) == [], (seed, tname)
-    assert fz.STATS["bad_status"] > 50
+    assert fz.STATS["bad_status"] > 50 and fz.STATS["details"] > 50
 
 
 def test_encoder_on_adversarial_values_vs_oracle(cv, oracle):

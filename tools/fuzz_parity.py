@@ -116,6 +116,7 @@ def one_round(seed, tname, hits):
                 if not np.array_equal(gm, wm):
                     errs.append(("masks", p, v))
     dec, doff, dst = dev.decode(return_status=True)
+    det = dev.error_details(dst)                # where every failed vector stopped, and the error's payload
     doff = np.asarray(doff)
     wdec, wst, _ = oracle.batch_decode(et, blob, byte_off, doff)
     STATS["vectors"] += nv
@@ -129,6 +130,11 @@ def one_round(seed, tname, hits):
         if dst[v] != wst[v]:
             if not count_mismatch(et, blob, byte_off, v):
                 errs.append(("decode status", v, int(dst[v]), int(wst[v])))
+        elif dst[v] != 0:
+            rc, k, payload = oracle.error_detail(et, blob[int(byte_off[v]):int(byte_off[v + 1])])
+            STATS["details"] = STATS.get("details", 0) + 1
+            if rc != dst[v] or (int(det[v, 0]), int(det[v, 1])) != (k, payload):
+                errs.append(("error detail", v, int(dst[v]), (int(det[v, 0]), int(det[v, 1])), (k, payload)))
         elif dst[v] == 0:
             a, b = int(doff[v]), int(doff[v + 1])
             STATS["elements_decoded"] += b - a
