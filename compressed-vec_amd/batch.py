@@ -334,6 +334,26 @@ class DeviceBatch:
         self._index_valid = indexed
         return res
 
+    def vector_items(self, v, start=0, stop=None):
+        """VectorItemIter over vector v of the resident batch (src/vector.rs:512-556): its values at positions
+        [start, stop) as a device tensor.  Only that vector is decoded (a one-vector view of the batch)."""
+        if not 0 <= v < self.n_vectors:
+            raise IndexError(v)
+        bo = self.d_byte_off[v:v + 2]
+        sb = self.d_sec_base[v:v + 2]
+        a, b = (int(x) for x in bo.cpu())
+        s0, s1 = (int(x) for x in sb.cpu())
+        # the blob pointer must stay 16-byte aligned: keep the batch's base and its absolute offsets
+        one = DeviceBatch(self.etype, self.d_bytes, bo.contiguous(), (sb - s0).contiguous(), 1, s1 - s0, self.n_bytes)
+        out = torch.zeros(max(s1 - s0, 1) * FIXED_LEN, dtype=TORCH_DTYPE[self.etype], device=self.device)
+        st = torch.zeros(1, dtype=torch.int32, device=self.device)
+        one.decode_async(out, status=st)
+        n = int.from_bytes(bytes(self.d_bytes[a + 8:a + 12].cpu().numpy()), "little") if b - a >= 16 else 0
+        if int(st.item()) != N.OK:
+            raise N.CodingError(int(st.item()))
+        stop = n if stop is None else min(stop, n)
+        return out[start:stop]
+
     def decode(self, add_const=None, return_status=False):
         """Returns (values, out_off): every vector padded to whole sections, vectors back to back."""
         out = torch.zeros(self.n_sections * FIXED_LEN, dtype=TORCH_DTYPE[self.etype], device=self.device)

@@ -364,6 +364,34 @@ cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_
                               uint8_t *h_bytes, size_t bytes_cap, uint64_t *h_byte_off /* n+1 */,
                               uint64_t *h_total_bytes);
 
+/* ---- appender handle: VectorAppender<T, W> (src/vector.rs:207-379) ------------------------------ */
+/* What the crate's VectorU32Appender / VectorU64Appender / VectorF32XorAppender do for one vector:
+ * values and nulls are appended, finish() returns the vector's bytes.  The handle keeps the appended
+ * values, the fill of the open section and the count of explicit null sections on the host (one
+ * vector is far below GPU launch granularity); finish() and reader() encode on the GPU and write that
+ * count into the header (num_null_sections, src/vector.rs:160-169, :321-327).  Not thread-safe: one
+ * handle per thread, like the reference's &mut self. */
+typedef struct cvec_appender cvec_appender;
+/* try_new (src/vector.rs:223-234): initial_capacity < 8 is CVEC_NOT_ENOUGH_SPACE, as the header write
+ * into a buffer that small fails in the reference. */
+cvec_status cvec_appender_new(int32_t etype, size_t initial_capacity, cvec_appender **out);
+void cvec_appender_free(cvec_appender *a);
+cvec_status cvec_appender_reset(cvec_appender *a);                                  /* :254-262 */
+uint64_t cvec_appender_num_elements(const cvec_appender *a);                        /* :381-384 */
+/* append (src/vector.rs:300-307) for n values in host memory (element type of the appender). */
+cvec_status cvec_appender_append(cvec_appender *a, const void *values, size_t n);
+cvec_status cvec_appender_append_nulls(cvec_appender *a, size_t num_nulls);         /* :311-335 */
+/* finish (src/vector.rs:344-370): pads with nulls to total_num_rows, writes the vector into out and
+ * resets the appender.  *len receives the vector's size; with out == NULL or cap too small the call
+ * returns CVEC_ERR_CAPACITY, *len says what is needed and the appender keeps its contents.
+ * CVEC_INVALID_NUM_ROWS when more values were appended than total_num_rows or total_num_rows exceeds
+ * u32; detail (nullable) then receives the two numbers of the reference's InvalidNumRows(usize, usize). */
+cvec_status cvec_appender_finish(cvec_appender *a, uint64_t total_num_rows, uint8_t *out, size_t cap, size_t *len,
+                                 uint64_t detail[2]);
+/* reader (src/vector.rs:372-378): the bytes of the vector as written so far, i.e. its complete
+ * sections; values in the open section are not visible yet.  Same out / cap / len rules as finish. */
+cvec_status cvec_appender_reader(cvec_appender *a, uint8_t *out, size_t cap, size_t *len);
+
 /* Test hook, no counterpart in the reference: makes the next *_batch call of the calling thread fail
  * with CVEC_ERR_HIP at chunk `chunk` (0-based) after that chunk's copies and kernels have been queued,
  * to exercise the error exit of the pipeline (which must wait for everything in flight before it

@@ -261,6 +261,90 @@ def test_reference_test_cases_through_the_api_mirror(cv):
     assert list(vecsink.vec[:4]) == [3.5, 4.0, 4.5, 5.0]
 
 
+def test_section_iteration_section256_sink_and_ranged_reads(cv, oracle):
+    """FixedSectIterator / Section256Sink (src/section.rs:846-884, src/sink.rs:195-232) and VectorItemIter
+    ranges (src/vector.rs:512-556) against the oracle's decode of the same bytes; the resident-batch ranged
+    read DeviceBatch.vector_items against the same."""
+    rng = np.random.default_rng(77)
+    app = cv.VectorU32Appender.try_new(512)
+    vals = rng.integers(0, 1000, size=700).astype(np.uint32)
+    app.append_many(vals)
+    app.append_nulls(256 - 700 % 256 + 512)               # rounds out section 3, then two explicit null sections
+    app.append_many(np.full(256, 9, dtype=np.uint32))     # a Const section
+    fin = app.finish(1800)
+    kinds = [int(k) for k in oracle.reader_sections(oracle.U32, fin)]
+    want = oracle.decode_to_vec(oracle.U32, fin)
+    r = cv.VectorReader.try_new(fin, "u32")
+    secs = r.sections()
+    assert [s.kind for s in secs] == kinds and sum(s.num_bytes for s in secs) == len(fin) - 16
+    assert [s.is_null() for s in secs] == [k == 0 for k in kinds] and kinds.count(0) >= 3 and 5 in kinds
+    sink = cv.Section256Sink("u32")
+    for s_ in secs:
+        sink.reset()
+        s_.decode(sink)
+        assert np.array_equal(sink.values, want[256 * s_.index:256 * s_.index + 256]), s_.index
+        s_.decode(sink)                                   # full: further values are ignored (src/sink.rs:214-219)
+        assert np.array_equal(sink.values, want[256 * s_.index:256 * s_.index + 256])
+    # through AddConstSink: wrapping add; a Null section yields the base itself
+    sink.reset()
+    secs[3].decode(cv.AddConstSink(7, sink))
+    assert secs[3].is_null() and np.all(sink.values == 7)
+    sink.reset()
+    secs[0].decode(cv.AddConstSink(0xffffffff, sink))
+    assert np.array_equal(sink.values, want[:256] - np.uint32(1))
+    # decode_to_sink into a Section256Sink leaves the first section there
+    sink.reset()
+    r.decode_to_sink(sink)
+    assert np.array_equal(sink.values, want[:256])
+    # ranged reads
+    assert np.array_equal(r.iterate(), want[:1800])
+    assert np.array_equal(r.iterate(250, 1030), want[250:1030]) and r.iterate(1700, 5000).size == 100
+    other = oracle.encode_all(oracle.U32, np.arange(900, dtype=np.uint32))
+    dev = cv.EncodedBatch.from_vectors("u32", [other, fin, other]).to_device()
+    assert np.array_equal(dev.vector_items(1, 250, 1030).cpu().numpy().view(np.uint32), want[250:1030])
+    assert np.array_equal(dev.vector_items(2).cpu().numpy().view(np.uint32), np.arange(900, dtype=np.uint32))
+    with pytest.raises(IndexError):
+        dev.vector_items(3)
+    # a damaged section: the sections before it still decode, the range behind it raises
+    bad = bytearray(fin)
+    bad[16 + secs[0].num_bytes + 3 + 1] = 0xf0            # second section, first octet: 16 nibbles in a u32 vector
+    rb = cv.VectorReader.try_new(bytes(bad), "u32")
+    assert np.array_equal(rb.iterate(0, 256), want[:256])
+    with pytest.raises(cv.CodingError):
+        rb.iterate(0, 300)
+    with pytest.raises(cv.CodingError):
+        rb.sections()[1].decode(cv.Section256Sink("u32"))
+
+
+def test_appender_handle_errors_and_reuse(cv, oracle):
+    """The C-ABI appender handle (cvec_appender_*): try_new's capacity check, InvalidNumRows with both numbers
+    (src/vector.rs:344-349), finish() resetting the appender (:368), reset(), and bytes equal to the oracle's
+    appender driven the same way."""
+    with pytest.raises(cv.CodingError) as e:
+        cv.VectorU64Appender.try_new(7)
+    assert e.value.name == "NotEnoughSpace"
+    a, o = cv.VectorF32XorAppender.try_new(64), oracle.Appender(oracle.F32, 64)
+    x = (np.arange(300) / 7.0).astype(np.float32)
+    for app in (a, o):
+        app.append_many(x)
+    with pytest.raises(cv.CodingError) as e:
+        a.finish(299)
+    assert e.value.name == "InvalidNumRows" and e.value.detail == (299, 300)
+    with pytest.raises(cv.CodingError) as e:
+        a.finish(2**32)
+    assert e.value.detail == (2**32, 2**32 - 1)
+    assert a.num_elements() == 300                        # a failed finish keeps the contents
+    assert a.finish(1000) == o.finish(1000)
+    assert a.num_elements() == 0
+    for app in (a, o):                                    # the handle is reusable after finish
+        app.append_nulls(700)
+        app.append_many(x[:10])
+    assert a.finish(710) == o.finish(710)
+    a.append_many(x)
+    a.reset()
+    assert a.num_elements() == 0 and a.finish(0) == o.finish(0)
+
+
 def test_appender_reader_sees_complete_sections_only(cv):
     """VectorAppender::reader (src/vector.rs:372-378) reads what has been encoded so far."""
     app = cv.VectorU32Appender.try_new(1024)
