@@ -215,7 +215,16 @@ cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_si
 
 /* VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of the batch.
  * Replaces src/vector.rs:458-464 with the sinks of src/sink.rs.  d_out (16-byte aligned) holds
- * 256 * n_sections elements of the batch's type (layout: see cvec_dbatch_view). */
+ * 256 * n_sections elements of the batch's type (layout: see cvec_dbatch_view).
+ *
+ * Values are decoded by the bitstream rule of the format, i.e. they are the values that were encoded.
+ * The reference crate itself does not always return those: when fewer than 34 bytes of the vector
+ * slice remain, its 32-bit unpacker falls back to preload_u32x8_nibbles (src/nibblepack_simd.rs:433-450,
+ * reached from :546-554, and for 64-bit vectors through src/nibblepacking.rs:431-434 when the octet's
+ * bits fit 32), which yields zeros for octets of 5 to 8 nibbles.  Well-formed vectors that end on a
+ * section boundary with such an octet (e.g. 2048-element f32 vectors of high-entropy data) therefore
+ * decode and filter differently here than in the crate, in those last lanes only; the filter pass
+ * follows the same rule as this decode. */
 cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
                             uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
                             void *stream);
