@@ -356,6 +356,19 @@ __global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
                         if constexpr (W == 4) v = (h0 >> 8) | (h1 << 24);
                         else v = ((uint64_t)(h0 >> 8) | ((uint64_t)h1 << 24)) | ((uint64_t)h2 << 56);
                     }
+                    // A run of Null sections (one zero byte each, src/section.rs:440-447: what append_nulls and sparse
+                    // data leave behind) is settled at once: as many as the 12 bytes just read show, the vector, its
+                    // announced section count and the window allow.
+                    uint32_t r = 1;
+                    if (b0 == K_NULL) {
+                        const uint32_t zeros = h0 ? (uint32_t)__builtin_ctz(h0) >> 3
+                                                  : (h1 ? 4u + ((uint32_t)__builtin_ctz(h1) >> 3) : (h2 ? 8u + ((uint32_t)__builtin_ctz(h2) >> 3) : 12u));
+                        r = zeros;
+                        r = r < rem ? r : rem;
+                        r = r < nslots - k ? r : nslots - k;
+                        r = r < wend - pos ? r : wend - pos;
+                        r = r < (uint32_t)(VS_MAX_RUN - run) ? r : (uint32_t)(VS_MAX_RUN - run);
+                    }
                     const uint32_t slot = slot0 + k;
                     if constexpr (MODE == MODE_DECODE) {
                         U y = v;
@@ -370,19 +383,23 @@ __global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
                         if constexpr (W == 4) yv = u32x4{(uint32_t)y, (uint32_t)y, (uint32_t)y, (uint32_t)y};
                         else yv = u32x4{(uint32_t)y, (uint32_t)((uint64_t)y >> 32), (uint32_t)y, (uint32_t)((uint64_t)y >> 32)};
                         const uint32_t o0 = slot * (uint32_t)(FIXED_LEN * W) + 16u * q;
-                        for (uint32_t j = 0; j < (uint32_t)(FIXED_LEN * W / 64); j++)
+                        for (uint32_t j = 0; j < r * (uint32_t)(FIXED_LEN * W / 64); j++)
                             __builtin_amdgcn_raw_buffer_store_b128(yv, orsrc, o0 + 64u * j, 0, 0);
-                        cnt += FIXED_LEN;
+                        cnt += r * (uint32_t)FIXED_LEN;
                     } else {
                         const bool all = b0 == K_NULL ? pa.match_zero != 0 : pred_match<ETYPE, NPRED>(pa, v);
-                        cnt += all ? (uint32_t)FIXED_LEN : 0u;
+                        cnt += all ? r * (uint32_t)FIXED_LEN : 0u;
                         if constexpr (MODE == MODE_FILTER_MASKS) {
-                            uint32_t *m = (uint32_t *)(masks + (uint64_t)slot * 32) + q;
-                            m[0] = m[4] = all ? ~0u : 0u;
+                            for (uint32_t j = 0; j < r; j++) {
+                                uint32_t *m = (uint32_t *)(masks + (uint64_t)(slot + j) * 32) + q;
+                                m[0] = m[4] = all ? ~0u : 0u;
+                            }
                         }
                     }
-                    pos += nb; k++; kvalid++;
-                    if (++run >= VS_MAX_RUN) go = false;
+                    pos += b0 == K_NULL ? r : nb;
+                    k += r; kvalid += r;
+                    run += (int)r;
+                    if (run >= VS_MAX_RUN) go = false;
                     continue;
                 }
                 const bool legal = ETYPE == CVEC_F32 ? b0 == K_XOR : b0 != K_XOR;

@@ -19,15 +19,28 @@ assert cv.lib().cvec_init(0) == 0
 if os.environ.get("PROBE_PATH"):
     assert cv.lib().cvec_set_read_path(int(os.environ["PROBE_PATH"])) == 0    # 1 = section-slot kernels, 2 = vector-streaming
 chunks = []
-for c0 in range(0, nvec, 16384):
-    n = min(16384, nvec - c0)
-    v = synth.batch_values_torch("f32_xor", n, 2048, v_first=c0)[0] if data == "sinusoid" else \
-        synth.splitmix_f32_torch(n, 2048, v_first=c0)[0]
-    chunks.append(v)
-vals = torch.cat(chunks)
-eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * 2048
-b = cv.encode_device("f32", vals, eo)
-pred = cv.make_pred(cv.F32, 3.0)
+if data == "sparse":          # the reference's very sparse u32 bench vector (benches/bench.rs:160-170), 26214 of them
+    nvec = int(sys.argv[2]) if len(sys.argv) > 2 else 26214
+    for c0 in range(0, nvec, 4096):
+        chunks.append(synth.batch_values_torch("u32_dense", min(4096, nvec - c0), 10000, v_first=c0)[0])
+    vals = torch.cat(chunks)
+    keep = torch.zeros(10000, dtype=torch.bool, device="cuda")
+    keep[2475:2525] = True
+    keep[7475:7525] = True
+    vals = torch.where(keep.repeat(nvec), vals, torch.zeros_like(vals))
+    eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * 10000
+    b = cv.encode_device("u32", vals, eo)
+    pred = cv.make_pred(cv.U32, 15)
+else:
+    for c0 in range(0, nvec, 16384):
+        n = min(16384, nvec - c0)
+        v = synth.batch_values_torch("f32_xor", n, 2048, v_first=c0)[0] if data == "sinusoid" else \
+            synth.splitmix_f32_torch(n, 2048, v_first=c0)[0]
+        chunks.append(v)
+    vals = torch.cat(chunks)
+    eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * 2048
+    b = cv.encode_device("f32", vals, eo)
+    pred = cv.make_pred(cv.F32, 3.0)
 for _ in range(20):
     b.filter_count_async(pred)
 torch.cuda.synchronize()
