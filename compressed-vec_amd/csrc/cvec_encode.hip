@@ -237,6 +237,12 @@ template <class U> __device__ inline OctInfo octet_info(const U x[4], int lane) 
 // load.  Branch-free loads let the compiler count them, so the loads of the next section stay in
 // flight under the work on this one.  Elements past `valid` become the zero padding of finish()
 // (src/vector.rs:352-355).
+typedef uint32_t __attribute__((__vector_size__(16))) u32x4_t;
+// Values are read once per pass and the encoded bytes written once: non-temporal loads and stores
+// (measured together: +3.5 % on f32, +2 % on u32, -2 % on u64 delta against the default policy).
+#ifndef CVEC_ENC_LD_AUX
+#define CVEC_ENC_LD_AUX 2
+#endif
 template <int ETYPE>
 __device__ inline void load_section(const typename EncT<ETYPE>::U *__restrict__ values, uint64_t e0, uint32_t valid,
                                     uint32_t avail, int lane, typename EncT<ETYPE>::U x[4]) {
@@ -244,12 +250,12 @@ __device__ inline void load_section(const typename EncT<ETYPE>::U *__restrict__ 
     typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(values + e0), 0, (int)(avail * W), 0x00020000);
     if constexpr (W == 4) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, 0, CVEC_ENC_LD_AUX);
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = v[i];
     } else {
-        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, 0, 0);
-        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, 16, 0);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, 0, CVEC_ENC_LD_AUX);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 32, 16, CVEC_ENC_LD_AUX);
         x[0] = (uint64_t)a[0] | ((uint64_t)a[1] << 32); x[1] = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
         x[2] = (uint64_t)b[0] | ((uint64_t)b[1] << 32); x[3] = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
     }
@@ -432,7 +438,7 @@ __device__ inline void image_copy_out(const uint32_t *buf, uint32_t phase, uint3
     const uint32_t npieces = (end + 15) >> 4;
     for (uint32_t d = lane; d < npieces; d += 64) {
         const uint32_t lo = 16 * d;
-        if (lo >= phase && lo + 16 <= end) *(uint4 *)(gdst + lo) = ((const uint4 *)buf)[d];
+        if (lo >= phase && lo + 16 <= end) __builtin_nontemporal_store(((const u32x4_t *)buf)[d], (u32x4_t *)(gdst + lo));
     }
     if (lane < 32) {
         const bool last = lane >= 16;
