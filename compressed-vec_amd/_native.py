@@ -13,6 +13,7 @@ MAX_PRED_VALUES = 16
 RESULT_WORDS = 4
 STATIC_SCRATCH_BYTES = 2 * 1024 * 1024
 PATH_AUTO, PATH_SLOTS, PATH_VSTREAM = 0, 1, 2
+TAIL_FORMAT, TAIL_REFERENCE = 0, 1
 
 OK = 0
 NOT_ENOUGH_SPACE, INPUT_TOO_SHORT, BAD_OFFSET, INVALID_SECTION_TYPE, INVALID_FORMAT, INVALID_NUM_ROWS, \
@@ -68,6 +69,7 @@ SIGNATURES = {
     "cvec_last_hip_error": (C.c_char_p, []),
     "cvec_status_name": (C.c_char_p, [C.c_int32]),
     "cvec_set_read_path": (C.c_int32, [C.c_int32]),
+    "cvec_set_tail_rule": (C.c_int32, [C.c_int32]),
     "cvec_timing_begin": (C.c_int32, [C.c_int32]),
     "cvec_timing_end": (C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(C.c_int32)]),
@@ -140,6 +142,13 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def set_tail_rule(rule):
+    """"format" (default): every octet decodes by the bitstream rule of the wire format, i.e. to the values that
+    were encoded.  "reference": the last octets of a vector decode the way the reference crate's tail fallback
+    does (cvec_set_tail_rule, CVEC_TAIL_REFERENCE).  Process-wide."""
+    check(lib().cvec_set_tail_rule({"format": TAIL_FORMAT, "reference": TAIL_REFERENCE}[rule]))
 
 
 def lib():

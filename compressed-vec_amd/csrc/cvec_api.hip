@@ -32,6 +32,7 @@ hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uin
                                  const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
                                  hipStream_t stream);
 void set_read_path(int path);
+void set_tail_rule(int rule);
 hipError_t launch_error_detail(int etype, const uint8_t *bytes, const uint64_t *byte_off, uint64_t n, const int32_t *status,
                                const uint32_t *valid, const uint8_t *parse_failed, uint64_t *detail, hipStream_t stream);
 hipError_t launch_merge_filter_pass(uint64_t n_vectors, uint64_t n_sections, const uint64_t *tmp_result,
@@ -407,6 +408,12 @@ cvec_status cvec_init(int device) {
 cvec_status cvec_set_read_path(int32_t path) {
     if (path != PATH_AUTO && path != PATH_SLOTS && path != PATH_VSTREAM) return CVEC_ERR_BAD_ARGUMENT;
     set_read_path(path);
+    return CVEC_OK;
+}
+
+cvec_status cvec_set_tail_rule(int32_t rule) {
+    if (rule != CVEC_TAIL_FORMAT && rule != CVEC_TAIL_REFERENCE) return CVEC_ERR_BAD_ARGUMENT;
+    set_tail_rule(rule);
     return CVEC_OK;
 }
 

@@ -696,6 +696,11 @@ hipError_t launch_vstream(int mode, const cvec_dbatch_view &b, const PredArgs &p
                           uint64_t *tag, hipStream_t stream);
 static int g_read_path = PATH_AUTO;
 void set_read_path(int path) { g_read_path = path; }
+// cvec_tailfix.hip
+hipError_t launch_ref_tail_fix(int etype, int decode, const cvec_dbatch_view &b, const uint64_t *desc, uint32_t *sec_res,
+                               const PredArgs &pa, const SinkArgs &sa, uint8_t *d_masks, void *d_out, hipStream_t stream);
+static int g_tail_rule = 0; // 0: the format's bitstream rule; 1: the reference crate's tail decoder
+void set_tail_rule(int rule) { g_tail_rule = rule; }
 
 template <int ETYPE>
 static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
@@ -710,7 +715,8 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     cookie |= 1;
     const uint64_t *check = phase == READ_INDEXED ? tag : nullptr;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
-    if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS) {
+    // (the reference's tail rule is applied by a pass over the section descriptors: the section-slot path)
+    if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS && g_tail_rule == 0) {
         // sparse batches of many vectors: one kernel, no section index, no per-section results (the timing slots of
         // the index and finalize kernels hold the memset and nothing)
         const bool vs = g_read_path == PATH_VSTREAM ? vstream_eligible(mode, b, true)
@@ -740,6 +746,8 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
         launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
                                phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, stream);
     timer_mark(rec, 3, stream);
+    if (g_tail_rule != 0 && phase != READ_INDEX_ONLY)
+        (void)launch_ref_tail_fix(ETYPE, mode == MODE_DECODE ? 1 : 0, b, desc, sec_res, pa, sa, d_masks, d_out, stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,

@@ -235,7 +235,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         }
     };
 
-    constexpr int HOLD = 4; // octets of decoded values held back per store burst (MODE_DECODE)
+#ifndef CVEC_HOLD
+#define CVEC_HOLD 4
+#endif
+    constexpr int HOLD = CVEC_HOLD; // octets of decoded values held back per store burst (MODE_DECODE)
     U hold[2 * HOLD];
     // back half of octet k: `newer` LDS reads were issued after its field reads
     auto back = [&](Oct &o, int k, auto newer) {

