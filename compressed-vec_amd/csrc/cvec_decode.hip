@@ -658,7 +658,14 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
     case 8: CVEC_LAUNCH_SEC(M, 8); break;                                                                           \
     default: CVEC_LAUNCH_SEC(M, 16); break;                                                                         \
     }
-        if (mode == MODE_DECODE) CVEC_LAUNCH_SEC(MODE_DECODE, 1);
+        if (mode == MODE_DECODE) {
+            // 32-bit output behind a blob of 5 to 35 % of its size: the pass is write-dominated, and non-temporal
+            // stores stream faster (2.25 -> 2.62 TB/s on dense u32; the second template argument is the store policy
+            // here).  Not below that: output that is mostly runs of one value (sparse vectors) loses a quarter.
+            const uint64_t raw = ns * (uint64_t)(FIXED_LEN * 4);
+            const bool nt_out = ETYPE != CVEC_U64 && n_bytes * 20 >= raw && n_bytes * 20 <= raw * 7;
+            if (nt_out) CVEC_LAUNCH_SEC(MODE_DECODE, 2); else CVEC_LAUNCH_SEC(MODE_DECODE, 1);
+        }
         else if (d_masks) { CVEC_LAUNCH_BUCKET(MODE_FILTER_MASKS); }
         else if (bucket == 1) {
             // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN

@@ -92,12 +92,11 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
 }
 
 typedef __amdgpu_buffer_rsrc_t out_rsrc_t;
-// Cache policy of the decoded output's stores: the default one.  Non-temporal stores are faster where the pass is
-// write-dominated (dense u32 at 0.77 B per element: 2.25 -> 2.62 TB/s) and slower where reads and writes balance
-// (f32 XOR: 2.14 -> 2.05 TB/s) or the output is long runs of one value (sparse vectors: 4.4 -> 2.7 TB/s).
-#ifndef CVEC_OUT_AUX
-#define CVEC_OUT_AUX 0
-#endif
+// Cache policy of the decoded output's stores.  Non-temporal stores are faster where the pass is write-dominated
+// (dense u32 at 0.77 B per element: 2.25 -> 2.62 TB/s) and slower where reads and writes balance (f32 XOR:
+// 2.14 -> 2.05 TB/s) or the output is long runs of one value (sparse vectors: 4.4 -> 2.7 TB/s).  In MODE_DECODE
+// the NPRED template parameter (no predicate there) carries the choice: 1 = default policy, 2 = non-temporal.
+template <int MODE, int NPRED> struct OutPolicy { static constexpr int AUX = (MODE == 1 /* MODE_DECODE */ && NPRED == 2) ? 2 : 0; };
 constexpr uint32_t OOFF_NONE = 0xffff0000u; // beyond any output descriptor (their ranges end below it): the store is dropped
 
 // MODE_DECODE addressing of k_sections: a buffer descriptor over the chunk's 16 consecutive section
@@ -334,11 +333,11 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
                     const uint32_t at = ooff + (uint32_t)(8 * (k - (HOLD - 1) + j) * W);
                     if constexpr (W == 4) {
                         typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{y0, y1}, orsrc, at, 0, CVEC_OUT_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{y0, y1}, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
                     } else {
                         typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
                         __builtin_amdgcn_raw_buffer_store_b128(
-                            u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)}, orsrc, at, 0, CVEC_OUT_AUX);
+                            u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)}, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
                     }
                 }
             }
@@ -430,7 +429,7 @@ __device__ inline void section_exact(const uint8_t *data, uint32_t lds_base, uin
                 } else { x[0] += (uint32_t)sa.base; x[1] += (uint32_t)sa.base; }
             }
             typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{x[0], x[1]}, orsrc, ooff + 32u * k, 0, CVEC_OUT_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{x[0], x[1]}, orsrc, ooff + 32u * k, 0, OutPolicy<MODE, NPRED>::AUX);
         } else {
             const bool m0 = pred_match<ETYPE, NPRED>(pa, x[0]), m1 = pred_match<ETYPE, NPRED>(pa, x[1]);
             cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);

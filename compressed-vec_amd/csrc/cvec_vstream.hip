@@ -384,7 +384,7 @@ __global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
                         else yv = u32x4{(uint32_t)y, (uint32_t)((uint64_t)y >> 32), (uint32_t)y, (uint32_t)((uint64_t)y >> 32)};
                         const uint32_t o0 = slot * (uint32_t)(FIXED_LEN * W) + 16u * q;
                         for (uint32_t j = 0; j < r * (uint32_t)(FIXED_LEN * W / 64); j++)
-                            __builtin_amdgcn_raw_buffer_store_b128(yv, orsrc, o0 + 64u * j, 0, CVEC_OUT_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(yv, orsrc, o0 + 64u * j, 0, 0);
                         cnt += r * (uint32_t)FIXED_LEN;
                     } else {
                         const bool all = b0 == K_NULL ? pa.match_zero != 0 : pred_match<ETYPE, NPRED>(pa, v);
