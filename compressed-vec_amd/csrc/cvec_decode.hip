@@ -705,7 +705,8 @@ static int g_read_path = PATH_AUTO;
 void set_read_path(int path) { g_read_path = path; }
 // cvec_tailfix.hip
 hipError_t launch_ref_tail_fix(int etype, int decode, const cvec_dbatch_view &b, const uint64_t *desc, uint32_t *sec_res,
-                               const PredArgs &pa, const SinkArgs &sa, uint8_t *d_masks, void *d_out, hipStream_t stream);
+                               const PredArgs &pa, const SinkArgs &sa, uint8_t *d_masks, void *d_out, const uint64_t *tag,
+                               uint64_t cookie, hipStream_t stream);
 static int g_tail_rule = 0; // 0: the format's bitstream rule; 1: the reference crate's tail decoder
 void set_tail_rule(int rule) { g_tail_rule = rule; }
 
@@ -754,7 +755,8 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
                                phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, stream);
     timer_mark(rec, 3, stream);
     if (g_tail_rule != 0 && phase != READ_INDEX_ONLY)
-        (void)launch_ref_tail_fix(ETYPE, mode == MODE_DECODE ? 1 : 0, b, desc, sec_res, pa, sa, d_masks, d_out, stream);
+        (void)launch_ref_tail_fix(ETYPE, mode == MODE_DECODE ? 1 : 0, b, desc, sec_res, pa, sa, d_masks, d_out, check, cookie,
+                                  stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,

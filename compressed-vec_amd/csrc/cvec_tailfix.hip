@@ -50,9 +50,12 @@ __global__ __launch_bounds__(256) void k_ref_tail_fix(const uint8_t *__restrict_
                                                       const uint64_t *__restrict__ sec_base, uint64_t n,
                                                       const uint64_t *__restrict__ desc, uint32_t *__restrict__ sec_res,
                                                       PredArgs pa, SinkArgs sa, int decode, uint8_t *__restrict__ masks,
-                                                      void *__restrict__ out_, uint64_t n_bytes) {
+                                                      void *__restrict__ out_, uint64_t n_bytes,
+                                                      const uint64_t *__restrict__ tag, uint64_t cookie) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
+    // descriptors reused from an earlier pass are only followed if they are this batch's (like k_sections)
+    if (tag != nullptr && *tag != cookie) return;
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const uint64_t vend = byte_off[v + 1];
@@ -156,14 +159,15 @@ __global__ __launch_bounds__(256) void k_ref_tail_fix(const uint8_t *__restrict_
 }
 
 hipError_t launch_ref_tail_fix(int etype, int decode, const cvec_dbatch_view &b, const uint64_t *desc, uint32_t *sec_res,
-                               const PredArgs &pa, const SinkArgs &sa, uint8_t *d_masks, void *d_out, hipStream_t stream) {
+                               const PredArgs &pa, const SinkArgs &sa, uint8_t *d_masks, void *d_out, const uint64_t *tag,
+                               uint64_t cookie, hipStream_t stream) {
     const uint64_t n = b.n_vectors;
     if (n == 0) return hipSuccess;
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     switch (etype) {
-    case CVEC_U32: k_ref_tail_fix<CVEC_U32><<<blocks, 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base, n, desc, sec_res, pa, sa, decode, d_masks, d_out, b.n_bytes); break;
-    case CVEC_F32: k_ref_tail_fix<CVEC_F32><<<blocks, 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base, n, desc, sec_res, pa, sa, decode, d_masks, d_out, b.n_bytes); break;
-    case CVEC_U64: k_ref_tail_fix<CVEC_U64><<<blocks, 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base, n, desc, sec_res, pa, sa, decode, d_masks, d_out, b.n_bytes); break;
+    case CVEC_U32: k_ref_tail_fix<CVEC_U32><<<blocks, 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base, n, desc, sec_res, pa, sa, decode, d_masks, d_out, b.n_bytes, tag, cookie); break;
+    case CVEC_F32: k_ref_tail_fix<CVEC_F32><<<blocks, 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base, n, desc, sec_res, pa, sa, decode, d_masks, d_out, b.n_bytes, tag, cookie); break;
+    case CVEC_U64: k_ref_tail_fix<CVEC_U64><<<blocks, 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base, n, desc, sec_res, pa, sa, decode, d_masks, d_out, b.n_bytes, tag, cookie); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

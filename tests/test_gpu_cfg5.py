@@ -226,6 +226,11 @@ def test_reference_tail_rule_on_ragged_vectors(cv, oracle, reference_rule, tname
         for v in range(0, 300, 7):
             _, wm = oracle.filter_count(et, blob[int(bo[v]):int(bo[v + 1])], p, return_masks=True)
             assert np.array_equal(masks[32 * int(sb[v]):32 * int(sb[v + 1])], np.asarray(wm, dtype=np.uint8).reshape(-1)), (p, v)
+    # over a resident section index as well
+    idx = cv.EncodedBatch(tname, blob, bo).to_device().build_index()
+    itotal, iper = idx.filter_count(nz[3].item(), per_vector=True)
+    wtotal, wper, _, _ = oracle.batch_filter_count(et, blob, bo, nz[3].item())
+    assert itotal == wtotal and np.array_equal(iper, wper)
     host = cv.EncodedBatch(tname, blob, bo)
     ht, hper = cv.filter_count_host(host, nz[3].item(), per_vector=True)
     wtotal, wper, _, _ = oracle.batch_filter_count(et, blob, bo, nz[3].item())
