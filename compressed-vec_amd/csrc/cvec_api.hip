@@ -18,7 +18,7 @@ uint64_t scan_scratch_words(uint64_t n);
 hipError_t launch_read(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                        uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
                        int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, uint64_t *tag,
-                       hipStream_t stream);
+                       uint32_t *work, hipStream_t stream);
 hipError_t timing_begin(int max_records);
 hipError_t timing_end(float ms[3], int *n_records);
 // cvec_filter_ops.hip
@@ -32,6 +32,10 @@ hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uin
                                  const int32_t *vstatus, const uint64_t *tag, uint32_t *valid, uint8_t *parse_failed,
                                  hipStream_t stream);
 void set_read_path(int path);
+#ifdef CVEC_PROBES
+hipError_t debug_fused_times(uint64_t *h_out);
+hipError_t debug_sections_times(uint64_t *h_out);
+#endif
 void set_tail_rule(int rule);
 hipError_t launch_error_detail(int etype, const uint8_t *bytes, const uint64_t *byte_off, uint64_t n, const int32_t *status,
                                const uint32_t *valid, const uint8_t *parse_failed, uint64_t *detail, hipStream_t stream);
@@ -406,10 +410,26 @@ cvec_status cvec_init(int device) {
 }
 
 cvec_status cvec_set_read_path(int32_t path) {
-    if (path != PATH_AUTO && path != PATH_SLOTS && path != PATH_VSTREAM) return CVEC_ERR_BAD_ARGUMENT;
+    if (path != PATH_AUTO && path != PATH_SLOTS && path != PATH_VSTREAM && path != PATH_FUSED) return CVEC_ERR_BAD_ARGUMENT;
     set_read_path(path);
     return CVEC_OK;
 }
+
+#ifdef CVEC_PROBES
+// probe build only: 2048 x 8 wall-clock stamps (100 MHz) of the last k_fused launch, per wave
+cvec_status cvec_debug_fused_times(uint64_t *h_out) {
+    HIP_TRY(cvec::debug_fused_times(h_out));
+    return CVEC_OK;
+}
+#endif
+
+#ifdef CVEC_PROBES
+// probe build only: 8192 x 2 wall-clock stamps (start, end) of the last k_sections launch, per wave
+cvec_status cvec_debug_sections_times(uint64_t *h_out) {
+    HIP_TRY(cvec::debug_sections_times(h_out));
+    return CVEC_OK;
+}
+#endif
 
 cvec_status cvec_set_tail_rule(int32_t rule) {
     if (rule != CVEC_TAIL_FORMAT && rule != CVEC_TAIL_REFERENCE) return CVEC_ERR_BAD_ARGUMENT;
@@ -435,12 +455,13 @@ cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_final
 }
 
 // Workspace layout (each part 256-byte aligned):
-//   desc[n_sections] u64 | sec_res[n_sections] u32 | vstatus[n_vectors] i32 | scan scratch
+//   desc[n_sections] u64 | sec_res[n_sections] u32 | vstatus[n_vectors] i32 | scan scratch | range counters
 struct ReadWs {
     uint64_t *desc;
     uint32_t *sec_res;
     int32_t *vstatus;
     uint64_t *scan; // 256 bytes or more of scratch: [0, 4) a spare result block, [8] and [9] the two tag words
+    uint32_t *work; // range counters of the section kernel: WORK_COUNTERS lines of 128 bytes, cleared by every pass
     uint64_t *tag;  // [0] whose section index the workspace holds (written by the index pass, cleared by a
                     // vector-streaming pass), [1] VS_MAGIC when the per-vector array holds valid-section counts
     size_t total;
@@ -454,6 +475,7 @@ static ReadWs carve_read_ws(void *base, uint64_t n_vectors, uint64_t n_sections)
     w.vstatus = (int32_t *)(b + off); off += align_up((n_vectors + 1) * 4, 256);
     w.scan = (uint64_t *)(b + off); off += align_up(scan_scratch_words(n_vectors) * 8, 256);
     w.tag = w.scan + 8;
+    w.work = (uint32_t *)(b + off); off += (size_t)WORK_COUNTERS * WORK_STRIDE * 4;
     w.total = off;
     return w;
 }
@@ -519,7 +541,7 @@ cvec_status cvec_index_dev(const cvec_dbatch_view *batch, void *d_workspace, siz
     // the index pass clears a result block as its side job; here that block is scratch of the workspace
     static_assert(CVEC_RESULT_WORDS * 8 <= 256, "the scan scratch is at least 256 bytes");
     hipError_t e = launch_read(0, READ_INDEX_ONLY, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, w.scan, nullptr,
-                               nullptr, nullptr, nullptr, nullptr, w.tag, (hipStream_t)stream);
+                               nullptr, nullptr, nullptr, nullptr, w.tag, w.work, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_index_dev");
     return CVEC_OK;
 }
@@ -579,7 +601,7 @@ static cvec_status filter_count_phase(int phase, const cvec_dbatch_view *batch, 
     SinkArgs sa;
     memset(&sa, 0, sizeof(sa));
     hipError_t e = launch_read(0, phase, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, d_per_vector, d_status,
-                               d_masks, nullptr, d_gate, w.tag, (hipStream_t)stream);
+                               d_masks, nullptr, d_gate, w.tag, w.work, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_filter_count_dev");
     return CVEC_OK;
 }
@@ -673,7 +695,7 @@ static cvec_status decode_phase(int phase, const cvec_dbatch_view *batch, const 
         sa.base = batch->etype == CVEC_U64 ? chain->add_const_bits : (chain->add_const_bits & 0xffffffffull);
     }
     hipError_t e = launch_read(1, phase, *batch, pa, sa, w.desc, w.sec_res, w.vstatus, d_result, nullptr, d_status,
-                               nullptr, d_out, nullptr, w.tag, (hipStream_t)stream);
+                               nullptr, d_out, nullptr, w.tag, w.work, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "cvec_decode_dev");
     return CVEC_OK;
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
                                                uint64_t padded_bytes, const uint8_t *__restrict__ gate,
                                                uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
                                                uint64_t *__restrict__ result, uint64_t *__restrict__ tag,
-                                               uint64_t cookie) {
+                                               uint64_t cookie, uint32_t *__restrict__ work) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     // One 4-byte load per section header (type byte + 16-bit length), pulled back inside the padded
     // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     // Whose index this workspace holds from now on (a gated index is nobody's): a later pass that reuses
     // the descriptors instead of walking the headers again checks it.
     if (v == 0) { tag[0] = gate ? 0ull : cookie; tag[1] = 0; }
+    if (v < WORK_COUNTERS) work[v * WORK_STRIDE] = 0; // the section kernel's range counters
     if (v >= n) return;
     const uint64_t start = byte_off[v], L = byte_off[v + 1] - start;
     const uint64_t slot0 = sec_base[v], nslots = sec_base[v + 1] - slot0;
@@ -257,6 +258,15 @@ struct ChunkPlan {
     uint32_t kind; //   kind (K_SKIP beyond the chunk)
 };
 
+#ifdef CVEC_PROBES
+// probe build: per-wave wall-clock stamps (100 MHz) of k_sections (start, end), read back by cvec_debug_sections_times
+__device__ uint64_t g_sec_stamps[8192 * 2];
+hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sec_stamps), sizeof(g_sec_stamps)); }
+#define SEC_STAMP(i) do { const uint32_t gw_ = blockIdx.x * SEC_WAVES + wave; if (lane == 0 && gw_ < 8192) g_sec_stamps[gw_ * 2 + (i)] = wall_clock64(); } while (0)
+#else
+#define SEC_STAMP(i) do { } while (0)
+#endif
+
 // k_sections: every wave is on its own.  A wave owns a contiguous range of section slots and an
 // 18 KiB staging region in LDS, and loops over chunks of up to 16 sections.  Per chunk: the bytes
 // prefetched into registers during the previous chunk's compute are written to the region; the next
@@ -272,7 +282,8 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
                                                           uint32_t *__restrict__ sec_res,
                                                           uint8_t *__restrict__ masks, void *__restrict__ out_,
                                                           const uint64_t *__restrict__ tag, uint64_t cookie,
-                                                          const uint8_t *__restrict__ gate) {
+                                                          const uint8_t *__restrict__ gate, uint32_t *__restrict__ work,
+                                                          uint32_t n_groups) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared<PIECES> sm;
     // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
@@ -281,9 +292,19 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // The slots are cut into ranges of sections_per_wave.  Wave g starts with range g; with range counters
+    // (`work`, zero at the start of the kernel) every further range goes to whichever wave asks first.  The
+    // issue arbiter of a SIMD prefers its older wave, so with equal shares the waves of the workgroup that
+    // reached a CU first finish a third earlier than those of the second one, which then run on alone at
+    // less than half the throughput of a pair (measured: 127 against 177 us); handed out on demand, the
+    // ranges keep every SIMD paired up until the batch is done.  Atomics on one address complete at about
+    // 7 ns apiece, so workgroup b shares counter b % n_groups (its own 128-byte line) with a few dozen waves
+    // only: the k-th range that counter c hands out is n_static + k * n_groups + c.
     const uint64_t sA = ((uint64_t)blockIdx.x * SEC_WAVES + wave) * sections_per_wave;
-    const uint64_t sB = sA + sections_per_wave < n_sections ? sA + sections_per_wave : n_sections;
-    if (sA >= sB) return;
+    if (sA >= n_sections) return;
+    uint64_t sB = sA + sections_per_wave < n_sections ? sA + sections_per_wave : n_sections; // end of the range being planned
+    const uint32_t n_static = gridDim.x * SEC_WAVES; // ranges that have an owner from the start
+    SEC_STAMP(0);
     uint8_t *data = sm.data[wave];
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)data);
     const uint32_t sec = (uint32_t)lane >> 2;
@@ -361,9 +382,15 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
 #pragma unroll
     for (int i = 0; i < PIECES; i++) R[i] = u32x4{0, 0, 0, 0};
     // The first pass of the loop has an empty current chunk: it only plans and loads chunk 0.
-    uint64_t s_cur = sA;
+    uint64_t s_cur = sA, s_next = sA;
     ChunkPlan cur;
     cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP;
+    // the wave's next range is asked for one range ahead: the counter's answer has a whole range to arrive
+    uint32_t ticket = 0;
+    const uint32_t group = blockIdx.x % n_groups;
+    uint32_t *const my_work = work != nullptr && (uint64_t)n_static * sections_per_wave < n_sections
+                                  ? work + (size_t)group * WORK_STRIDE : nullptr; // nullptr: no range is left to hand out
+    if (my_work != nullptr && lane == 0) ticket = atomicAdd(my_work, 1u);
     uint64_t d_next = load_desc(sA);
     // A chunk's per-section results are stored one loop pass later, behind the wait for the prefetched
     // bytes: loads and stores share one in-order counter only among their own kind, so a wait for loads
@@ -394,7 +421,6 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
         // ---- plan the next chunk and start its loads ------------------------------------------------------------
         // (unconditional, so that the staging registers never become conditionally assigned: past the
         // wave's range the plan is empty and the loads fetch nothing)
-        uint64_t s_next = s_cur + cur.n;
         ChunkPlan nxt = plan(s_next, d_next);
         if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
             // Behind a selective gate most chunks are closed as a whole: their results (count 0, empty
@@ -428,8 +454,17 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
                 nxt = plan(s_next, d_next);
             }
         }
+        // where the chunk after the next one starts: behind it, or in the wave's next range once this one is used up
+        // (ahead of the staging loads: the counter's answer is then the only thing the wait for it can wait for)
+        uint64_t s_after = s_next + nxt.n;
+        if (my_work != nullptr && s_after >= sB && nxt.n != 0) {
+            const uint64_t r = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * n_groups + group + n_static;
+            s_after = r * sections_per_wave < n_sections ? r * sections_per_wave : n_sections;
+            sB = s_after + sections_per_wave < n_sections ? s_after + sections_per_wave : n_sections;
+            if (s_after < n_sections && lane == 0) ticket = atomicAdd(my_work, 1u);
+        }
         issue_loads(nxt);
-        d_next = load_desc(s_next + nxt.n);
+        d_next = load_desc(s_after);
         // ---- walk + decode the current chunk ----------------------------------------------------------------------
         const bool has_octets = cur.kind == K_NP || cur.kind == K_DELTA || cur.kind == K_XOR || cur.kind == K_RAW;
         if (MODE != MODE_DECODE && cur.n != 0 && __ballot(has_octets) == 0) {
@@ -469,6 +504,7 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
         if (nxt.n == 0) break;
         s_cur = s_next;
         cur = nxt;
+        s_next = s_after;
     }
     if (res_pending) sec_res[res_slot] = res_word;
     if constexpr (MODE == MODE_FILTER_MASKS) {
@@ -477,6 +513,7 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
             m[0] = mk_lo; m[4] = mk_hi;
         }
     }
+    SEC_STAMP(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -529,9 +566,17 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ s
     }
 }
 
+// Start of a pass over a resident index (no index pass in front of it): clears the result block that k_finalize
+// accumulates into and the section kernel's range counter.
+__global__ void k_begin_indexed(uint64_t *__restrict__ result, uint32_t *__restrict__ work) {
+    if (threadIdx.x < CVEC_RESULT_WORDS) result[threadIdx.x] = 0;
+    if (threadIdx.x < WORK_COUNTERS) work[threadIdx.x * WORK_STRIDE] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+constexpr int RANGES_PER_WAVE = 16; // section ranges per wave of a full launch when they are handed out on demand
 
 // Optional per-kernel timing of the read path: when armed, every launch_read records a pair of HIP
 // events around each of its three kernels on the launch stream.
@@ -608,7 +653,7 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
 template <int ETYPE>
 static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
                             const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, const uint64_t *tag,
-                            uint64_t cookie, const uint8_t *d_gate, uint64_t n_bytes, hipStream_t stream) {
+                            uint64_t cookie, const uint8_t *d_gate, uint64_t n_bytes, uint32_t *work, hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).  Count-only passes over a batch whose average
@@ -630,10 +675,22 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 2) small = count_only;
         const int wgcu = wgcu_env > 0 ? wgcu_env : (small ? 3 : 2);
         const uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
+        // `work` (a counter that is zero when the kernel starts; not for gated passes, whose waves skip ahead in
+        // their own ranges): ranges an eighth of a wave's even share, handed out on demand (see k_sections).
+        // Without it every wave gets one range of that even share.
+        if (d_gate != nullptr) work = nullptr;
         uint64_t per = (ns + nwaves_max - 1) / nwaves_max;
+#ifdef CVEC_PROBES
+        static const int rpw = [] { const char *e = getenv("CVEC_RANGES_PER_WAVE"); return e ? atoi(e) : RANGES_PER_WAVE; }();
+        if (rpw <= 0) work = nullptr;
+#else
+        constexpr int rpw = RANGES_PER_WAVE;
+#endif
+        if (work != nullptr) per = (per + rpw - 1) / rpw;
         per = (per + TILE - 1) / TILE * TILE;
         if (per < 2 * TILE) per = 2 * TILE;
-        const uint64_t nwaves = (ns + per - 1) / per;
+        uint64_t nwaves = (ns + per - 1) / per; // ranges
+        if (nwaves > nwaves_max) nwaves = nwaves_max;
         const uint32_t nwg = (uint32_t)((nwaves + SEC_WAVES - 1) / SEC_WAVES);
         SinkArgs sa2 = sa;
         sa2._pad = (uint32_t)ablate; // always 0 in the product build
@@ -644,7 +701,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
 #define CVEC_LAUNCH_SEC_P(M, N, P)                                                                                  \
     k_sections<ETYPE, M, N, P><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
-                                                                tag, cookie, d_gate)
+                                                                tag, cookie, d_gate, work, nwg < (uint32_t)WORK_COUNTERS ? nwg : (uint32_t)WORK_COUNTERS)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
         if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES_SMALL);     \
@@ -689,7 +746,7 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     SinkArgs sa;
     memset(&pa, 0, sizeof(pa));
     memset(&sa, 0, sizeof(sa));
-    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, stream);
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, nullptr, stream);
     return hipGetLastError();
 }
 
@@ -701,6 +758,12 @@ bool vstream_eligible(int mode, const cvec_dbatch_view &b, bool forced);
 hipError_t launch_vstream(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint32_t *nvalid,
                           uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
                           uint64_t *tag, hipStream_t stream);
+// cvec_fused.hip
+bool fused_possible(const cvec_dbatch_view &b);
+bool fused_eligible(int mode, const cvec_dbatch_view &b, bool has_masks);
+hipError_t launch_fused(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
+                        uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
+                        uint8_t *d_masks, void *d_out, uint64_t *tag, uint64_t cookie, hipStream_t stream);
 static int g_read_path = PATH_AUTO;
 void set_read_path(int path) { g_read_path = path; }
 // cvec_tailfix.hip
@@ -714,7 +777,7 @@ template <int ETYPE>
 static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                           uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result,
                           uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
-                          const uint8_t *d_gate, uint64_t *tag, hipStream_t stream) {
+                          const uint8_t *d_gate, uint64_t *tag, uint32_t *work, hipStream_t stream) {
     const uint64_t n = b.n_vectors, ns = b.n_sections;
     // identifies the batch whose index the workspace holds: pointers and shape, never zero
     uint64_t cookie = 0x9e3779b97f4a7c15ull;
@@ -740,19 +803,35 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
             timer_mark(rec, 5, stream);
             return;
         }
+        // batches of many short vectors: one kernel that walks the headers of its own vectors ahead of its octet
+        // loop and folds the per-vector results at the end (the timing slots hold the result-clearing kernel, the
+        // kernel itself and nothing)
+        const bool fu = g_read_path == PATH_FUSED ? fused_possible(b)
+                                                  : (g_read_path == PATH_AUTO && fused_eligible(mode, b, d_masks != nullptr));
+        if (fu) {
+            timer_mark(rec, 0, stream);
+            timer_mark(rec, 1, stream);
+            timer_mark(rec, 2, stream);
+            (void)launch_fused(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks, d_out, tag,
+                               cookie, stream);
+            timer_mark(rec, 3, stream);
+            timer_mark(rec, 4, stream);
+            timer_mark(rec, 5, stream);
+            return;
+        }
     }
     timer_mark(rec, 0, stream);
     if (phase != READ_INDEXED)
         k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
                                                                                      n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
-                                                                                     vstatus, d_result, tag, cookie);
+                                                                                     vstatus, d_result, tag, cookie, work);
     else
-        (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream); // k_index does this otherwise
+        k_begin_indexed<<<1, 64, 0, stream>>>(d_result, work); // k_index does this otherwise
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)
         launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
-                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, stream);
+                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, work, stream);
     timer_mark(rec, 3, stream);
     if (g_tail_rule != 0 && phase != READ_INDEX_ONLY)
         (void)launch_ref_tail_fix(ETYPE, mode == MODE_DECODE ? 1 : 0, b, desc, sec_res, pa, sa, d_masks, d_out, check, cookie,
@@ -767,19 +846,19 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
 hipError_t launch_read(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
                        uint64_t *desc, uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector,
                        int32_t *d_status, uint8_t *d_masks, void *d_out, const uint8_t *d_gate, uint64_t *tag,
-                       hipStream_t stream) {
+                       uint32_t *work, hipStream_t stream) {
     switch (b.etype) {
     case CVEC_U32:
         launch_read_t<CVEC_U32>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
-                                d_masks, d_out, d_gate, tag, stream);
+                                d_masks, d_out, d_gate, tag, work, stream);
         break;
     case CVEC_U64:
         launch_read_t<CVEC_U64>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
-                                d_masks, d_out, d_gate, tag, stream);
+                                d_masks, d_out, d_gate, tag, work, stream);
         break;
     case CVEC_F32:
         launch_read_t<CVEC_F32>(mode, phase, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status,
-                                d_masks, d_out, d_gate, tag, stream);
+                                d_masks, d_out, d_gate, tag, work, stream);
         break;
     default: return hipErrorInvalidValue;
     }
