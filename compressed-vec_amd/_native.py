@@ -12,7 +12,7 @@ PRED_EQ, PRED_ONEOF = 0, 1
 MAX_PRED_VALUES = 16
 RESULT_WORDS = 4
 STATIC_SCRATCH_BYTES = 2 * 1024 * 1024
-PATH_AUTO, PATH_SLOTS, PATH_VSTREAM, PATH_FUSED = 0, 1, 2, 3
+PATH_AUTO, PATH_SLOTS, PATH_VSTREAM = 0, 1, 2
 TAIL_FORMAT, TAIL_REFERENCE = 0, 1
 
 OK = 0

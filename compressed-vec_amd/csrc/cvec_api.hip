@@ -33,7 +33,6 @@ hipError_t launch_valid_sections(const uint64_t *sec_base, uint64_t n, const uin
                                  hipStream_t stream);
 void set_read_path(int path);
 #ifdef CVEC_PROBES
-hipError_t debug_fused_times(uint64_t *h_out);
 hipError_t debug_sections_times(uint64_t *h_out);
 #endif
 void set_tail_rule(int rule);
@@ -410,18 +409,10 @@ cvec_status cvec_init(int device) {
 }
 
 cvec_status cvec_set_read_path(int32_t path) {
-    if (path != PATH_AUTO && path != PATH_SLOTS && path != PATH_VSTREAM && path != PATH_FUSED) return CVEC_ERR_BAD_ARGUMENT;
+    if (path != PATH_AUTO && path != PATH_SLOTS && path != PATH_VSTREAM) return CVEC_ERR_BAD_ARGUMENT;
     set_read_path(path);
     return CVEC_OK;
 }
-
-#ifdef CVEC_PROBES
-// probe build only: 2048 x 8 wall-clock stamps (100 MHz) of the last k_fused launch, per wave
-cvec_status cvec_debug_fused_times(uint64_t *h_out) {
-    HIP_TRY(cvec::debug_fused_times(h_out));
-    return CVEC_OK;
-}
-#endif
 
 #ifdef CVEC_PROBES
 // probe build only: 8192 x 2 wall-clock stamps (start, end) of the last k_sections launch, per wave

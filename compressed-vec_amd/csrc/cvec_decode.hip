@@ -248,6 +248,17 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
 
 namespace cvec {
 
+// largest value over the wave
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141 /* row_half_mirror */, 0xf, 0xf, false));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140 /* row_mirror */, 0xf, 0xf, false));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    return max(max(a, b), max(c, d));
+}
+
 // Plan of one chunk: the longest run of sections from s whose span fits a staging region.
 struct ChunkPlan {
     uint64_t gb;   // 128-byte aligned blob offset of the span
@@ -387,10 +398,16 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
     cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP;
     // the wave's next range is asked for one range ahead: the counter's answer has a whole range to arrive
     uint32_t ticket = 0;
-    const uint32_t group = blockIdx.x % n_groups;
-    uint32_t *const my_work = work != nullptr && (uint64_t)n_static * sections_per_wave < n_sections
-                                  ? work + (size_t)group * WORK_STRIDE : nullptr; // nullptr: no range is left to hand out
-    if (my_work != nullptr && lane == 0) ticket = atomicAdd(my_work, 1u);
+    // the counter this wave draws from: one of its XCD's (n_groups / 8 per XCD, so that a counter's line stays in one
+    // L2), later one that has ranges left
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; // HW_REG_XCC_ID[3:0]
+    uint32_t group = n_groups >= 8 ? xcc * (n_groups >> 3) + (blockIdx.x >> 3) % (n_groups >> 3) : blockIdx.x % n_groups;
+    const uint64_t n_ranges = (n_sections + sections_per_wave - 1) / sections_per_wave;
+    const bool dyn = work != nullptr && n_ranges > n_static; // otherwise no range is left to hand out
+    const uint32_t n_dyn = dyn ? (uint32_t)(n_ranges - n_static) : 0u;
+    // ranges counter g has to hand out: the indices j < n_dyn with j % n_groups == g
+    auto quota = [&](uint32_t g) -> uint32_t { return g < n_dyn ? (n_dyn - g + n_groups - 1) / n_groups : 0u; };
+    if (dyn && lane == 0) ticket = atomicAdd(work + (size_t)group * WORK_STRIDE, 1u);
     uint64_t d_next = load_desc(sA);
     // A chunk's per-section results are stored one loop pass later, behind the wait for the prefetched
     // bytes: loads and stores share one in-order counter only among their own kind, so a wait for loads
@@ -457,11 +474,36 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
         // where the chunk after the next one starts: behind it, or in the wave's next range once this one is used up
         // (ahead of the staging loads: the counter's answer is then the only thing the wait for it can wait for)
         uint64_t s_after = s_next + nxt.n;
-        if (my_work != nullptr && s_after >= sB && nxt.n != 0) {
-            const uint64_t r = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ticket) * n_groups + group + n_static;
-            s_after = r * sections_per_wave < n_sections ? r * sections_per_wave : n_sections;
-            sB = s_after + sections_per_wave < n_sections ? s_after + sections_per_wave : n_sections;
-            if (s_after < n_sections && lane == 0) ticket = atomicAdd(my_work, 1u);
+        if (dyn && s_after >= sB && nxt.n != 0) {
+            uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+            bool ok = t < quota(group);
+            // The wave's counter has run dry: it moves to the counter with most ranges left (one load fetches all
+            // of them) and asks there.  Only the last passes of a wave get here, so this wait is not hidden.
+            for (int tries = 0; tries < 4 && !ok; tries++) {
+                uint32_t key = 0; // ranges left << 8 | counter, the lane's best
+                for (uint32_t g = (uint32_t)lane; g < n_groups; g += 64) {
+                    const uint32_t v = __hip_atomic_load(work + (size_t)g * WORK_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t q = quota(g);
+                    const uint32_t left = v < q ? q - v : 0u;
+                    const uint32_t k = ((left < 0xffffffu ? left : 0xffffffu) << 8) | g;
+                    key = k > key ? k : key;
+                }
+                const uint32_t best = wave_max_u32(key);
+                if ((best >> 8) == 0) break;
+                group = best & 255u;
+                uint32_t tt = 0;
+                if (lane == 0) tt = atomicAdd(work + (size_t)group * WORK_STRIDE, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tt);
+                ok = t < quota(group);
+            }
+            if (ok) {
+                s_after = ((uint64_t)n_static + (uint64_t)t * n_groups + group) * sections_per_wave;
+                sB = s_after + sections_per_wave < n_sections ? s_after + sections_per_wave : n_sections;
+                if (lane == 0) ticket = atomicAdd(work + (size_t)group * WORK_STRIDE, 1u);
+            } else {
+                s_after = n_sections;
+                sB = n_sections;
+            }
         }
         issue_loads(nxt);
         d_next = load_desc(s_after);
@@ -570,13 +612,14 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ s
 // accumulates into and the section kernel's range counter.
 __global__ void k_begin_indexed(uint64_t *__restrict__ result, uint32_t *__restrict__ work) {
     if (threadIdx.x < CVEC_RESULT_WORDS) result[threadIdx.x] = 0;
-    if (threadIdx.x < WORK_COUNTERS) work[threadIdx.x * WORK_STRIDE] = 0;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)WORK_COUNTERS; i += blockDim.x) work[i * WORK_STRIDE] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 constexpr int RANGES_PER_WAVE = 16; // section ranges per wave of a full launch when they are handed out on demand
+constexpr int WORK_GROUPS = 128; // range counters in use (of the workspace's WORK_COUNTERS): 16 waves per counter in a full launch
 
 // Optional per-kernel timing of the read path: when armed, every launch_read records a pair of HIP
 // events around each of its three kernels on the launch stream.
@@ -681,6 +724,11 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (d_gate != nullptr) work = nullptr;
         uint64_t per = (ns + nwaves_max - 1) / nwaves_max;
 #ifdef CVEC_PROBES
+        static const uint32_t n_groups_max = [] { const char *e = getenv("CVEC_WORK_GROUPS"); const int x = e ? atoi(e) : WORK_GROUPS; return (uint32_t)(x >= 1 && x <= WORK_COUNTERS ? x : WORK_GROUPS); }();
+#else
+        constexpr uint32_t n_groups_max = WORK_GROUPS;
+#endif
+#ifdef CVEC_PROBES
         static const int rpw = [] { const char *e = getenv("CVEC_RANGES_PER_WAVE"); return e ? atoi(e) : RANGES_PER_WAVE; }();
         if (rpw <= 0) work = nullptr;
 #else
@@ -701,7 +749,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
 #define CVEC_LAUNCH_SEC_P(M, N, P)                                                                                  \
     k_sections<ETYPE, M, N, P><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
-                                                                tag, cookie, d_gate, work, nwg < (uint32_t)WORK_COUNTERS ? nwg : (uint32_t)WORK_COUNTERS)
+                                                                tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
         if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES_SMALL);     \
@@ -758,12 +806,6 @@ bool vstream_eligible(int mode, const cvec_dbatch_view &b, bool forced);
 hipError_t launch_vstream(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint32_t *nvalid,
                           uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
                           uint64_t *tag, hipStream_t stream);
-// cvec_fused.hip
-bool fused_possible(const cvec_dbatch_view &b);
-bool fused_eligible(int mode, const cvec_dbatch_view &b, bool has_masks);
-hipError_t launch_fused(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint64_t *desc,
-                        uint32_t *sec_res, int32_t *vstatus, uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status,
-                        uint8_t *d_masks, void *d_out, uint64_t *tag, uint64_t cookie, hipStream_t stream);
 static int g_read_path = PATH_AUTO;
 void set_read_path(int path) { g_read_path = path; }
 // cvec_tailfix.hip
@@ -803,22 +845,6 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
             timer_mark(rec, 5, stream);
             return;
         }
-        // batches of many short vectors: one kernel that walks the headers of its own vectors ahead of its octet
-        // loop and folds the per-vector results at the end (the timing slots hold the result-clearing kernel, the
-        // kernel itself and nothing)
-        const bool fu = g_read_path == PATH_FUSED ? fused_possible(b)
-                                                  : (g_read_path == PATH_AUTO && fused_eligible(mode, b, d_masks != nullptr));
-        if (fu) {
-            timer_mark(rec, 0, stream);
-            timer_mark(rec, 1, stream);
-            timer_mark(rec, 2, stream);
-            (void)launch_fused(mode, b, pa, sa, desc, sec_res, vstatus, d_result, d_per_vector, d_status, d_masks, d_out, tag,
-                               cookie, stream);
-            timer_mark(rec, 3, stream);
-            timer_mark(rec, 4, stream);
-            timer_mark(rec, 5, stream);
-            return;
-        }
     }
     timer_mark(rec, 0, stream);
     if (phase != READ_INDEXED)
@@ -826,7 +852,7 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
                                                                                      n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
                                                                                      vstatus, d_result, tag, cookie, work);
     else
-        k_begin_indexed<<<1, 64, 0, stream>>>(d_result, work); // k_index does this otherwise
+        k_begin_indexed<<<1, 256, 0, stream>>>(d_result, work); // k_index does this otherwise
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)

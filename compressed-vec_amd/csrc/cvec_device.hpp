@@ -24,10 +24,10 @@ __host__ __device__ inline uint64_t header_slots(uint32_t num_elements, uint64_t
 }
 
 enum { READ_ALL = 0, READ_INDEX_ONLY = 1, READ_INDEXED = 2 }; // phases of a read operation (launch_read)
-enum { PATH_AUTO = 0, PATH_SLOTS = 1, PATH_VSTREAM = 2, PATH_FUSED = 3 }; // which read kernel serves an ungated, unindexed pass
+enum { PATH_AUTO = 0, PATH_SLOTS = 1, PATH_VSTREAM = 2 }; // which read kernel serves an ungated, unindexed pass
 
 // Range counters of the section kernel in a read workspace: WORK_COUNTERS counters, each on a 128-byte line of its own.
-constexpr int WORK_COUNTERS = 64;
+constexpr int WORK_COUNTERS = 256;
 constexpr int WORK_STRIDE = 32; // in 32-bit words
 
 // Second tag word of a read workspace: set when its per-vector array holds the valid-section counts of a
