@@ -287,7 +287,7 @@ hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_
 // stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
 // No barriers and no cross-wave traffic.
 template <int ETYPE, int MODE, int NPRED, int PIECES>
-__global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2) void k_sections(const uint8_t *__restrict__ bytes,
+__global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_TINY ? 4 : (PIECES <= REGION_PIECES_SMALL ? 3 : 2)) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
                                                           uint32_t *__restrict__ sec_res,
@@ -575,13 +575,22 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ s
     const bool stale = tag != nullptr && *tag != cookie; // the section pass did not run: see k_sections
     if (v < n) {
         const uint64_t a = sec_base[v], b = stale ? a : sec_base[v + 1];
-        for (uint64_t s = a; s < b; s++) {
-            const uint32_t r = sec_res[s];
-            if (r >> 16) { st = r >> 16; break; } // the reference's iteration stops at the first failing section
-            cnt += r & 0xffffu;
+        const uint32_t hst = (uint32_t)vstatus[v];
+        // eight result words per round trip (the loads of a round do not depend on each other)
+        for (uint64_t s = a; s < b && !st; s += 8) {
+            uint32_t r[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = s + j < b ? sec_res[s + j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (!st) {
+                    if (r[j] >> 16) st = r[j] >> 16; // the reference's iteration stops at the first failing section
+                    else cnt += r[j] & 0xffffu;
+                }
+            }
         }
         if (stale) st = CVEC_ERR_WORKSPACE;
-        if (!st) st = (uint32_t)vstatus[v];
+        if (!st) st = hst;
         if (per_vec) per_vec[v] = cnt;
         if (status_out) status_out[v] = (int32_t)st;
     }
@@ -714,9 +723,17 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
 #endif
         const bool count_only = mode != MODE_DECODE && d_masks == nullptr;
         bool small = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL);
-        if (shape_env == 1) small = false;
-        if (shape_env == 2) small = count_only;
-        const int wgcu = wgcu_env > 0 ? wgcu_env : (small ? 3 : 2);
+        // A third shape, 6 KiB regions at four workgroups per CU, for count-only passes over batches whose sections
+        // average at most 378 bytes (dense integers, deltas): dense u32 0.202 -> 0.190 ms per GiB, u64 delta 0.171 ->
+        // 0.169.  (Decode passes were measured on it too and lose 3 to 6 %: more waves interleave more partial-line
+        // stores; they keep the 18 KiB shape.)
+        bool tiny = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_TINY);
+        if (shape_env == 1) small = tiny = false;
+        if (shape_env == 2) { small = count_only; tiny = false; }
+        if (shape_env == 3) tiny = count_only;
+        if (shape_env == 4) tiny = false;
+        if (tiny) small = false;
+        const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
         const uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
         // `work` (a counter that is zero when the kernel starts; not for gated passes, whose waves skip ahead in
         // their own ranges): ranges an eighth of a wave's even share, handed out on demand (see k_sections).
@@ -736,7 +753,12 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
 #endif
         if (work != nullptr) per = (per + rpw - 1) / rpw;
         per = (per + TILE - 1) / TILE * TILE;
-        if (per < 2 * TILE) per = 2 * TILE;
+#ifdef CVEC_PROBES
+        static const int min_chunks = [] { const char *e = getenv("CVEC_RANGE_MIN_CHUNKS"); return e ? atoi(e) : 2; }();
+#else
+        constexpr int min_chunks = 2;
+#endif
+        if (per < (uint64_t)min_chunks * TILE) per = (uint64_t)min_chunks * TILE;
         uint64_t nwaves = (ns + per - 1) / per; // ranges
         if (nwaves > nwaves_max) nwaves = nwaves_max;
         const uint32_t nwg = (uint32_t)((nwaves + SEC_WAVES - 1) / SEC_WAVES);
@@ -752,7 +774,11 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
                                                                 tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
-        if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES_SMALL);     \
+        /* (the conditional constants keep the shapes a mode never takes from being instantiated) */                \
+        if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && tiny)                                                    \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_TINY : REGION_PIECES)); \
+        else if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small)                                              \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_SMALL : REGION_PIECES)); \
         else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES);                                                                \
     } while (0)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \

@@ -983,19 +983,21 @@ def test_reference_bench_configurations_vs_oracle(cv, oracle, name):
         assert (kinds == 0).sum() >= 36                         # Null sections: the short-circuit path
 
 
-def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle):
-    """Count-only passes pick 12 KiB staging regions (three workgroups per CU) when 16 average sections fit
-    them, 18 KiB ones otherwise; a batch of small sections with a few vectors of incompressible ones mixed
-    in runs the small shape with chunks that break early, and must count like the oracle either way."""
+@pytest.mark.parametrize("top,lo,hi", [(200, 0, 378), (1 << 15, 379, 700)])
+def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle, top, lo, hi):
+    """Count-only passes pick 6 KiB staging regions (four workgroups per CU) or 12 KiB ones (three) when 16
+    average sections fit them, 18 KiB ones otherwise; a batch of small sections with a few vectors of
+    incompressible ones mixed in runs a small shape with chunks that break early, and must count like the
+    oracle either way."""
     rng = np.random.default_rng(77)
-    small = [rng.integers(1, 200, size=int(rng.integers(200, 3000))).astype(np.uint32) for _ in range(300)]
+    small = [rng.integers(1, top, size=int(rng.integers(200, 3000))).astype(np.uint32) for _ in range(300)]
     big = [rng.integers(0, 1 << 32, size=2048, dtype=np.uint64).astype(np.uint32) for _ in range(6)]
     vecs = small[:100] + big[:3] + small[100:] + big[3:]
     eo = np.concatenate([[0], np.cumsum([v.size for v in vecs])]).astype(np.uint64)
     vals = np.concatenate(vecs)
     blob, bo = oracle.batch_encode(oracle.U32, vals, eo)
     dev = cv.EncodedBatch("u32", blob, bo).to_device()
-    assert dev.n_bytes / dev.n_sections < 700                  # the launcher's rule picks the small shape
+    assert lo <= dev.n_bytes // dev.n_sections <= hi           # the launcher's rule picks the 6 KiB / the 12 KiB shape
     for p in (7, [7, 9, 150], int(big[0][5])):
         total, per = dev.filter_count(p, per_vector=True)
         wtotal, wper, _, rc = oracle.batch_filter_count(oracle.U32, blob, bo, p)
