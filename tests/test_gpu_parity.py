@@ -444,6 +444,49 @@ def test_malformed_vectors_report_status_and_partial_counts(cv, oracle):
     assert np.array_equal(dev.error_details(dst), det)
 
 
+def test_total_only_pass_equals_the_per_vector_pass(cv, oracle):
+    """A pass that asks for nothing but the result block takes the section kernel's own sums as the total when no
+    vector header and no section failed, and folds per vector otherwise.  Both ways must give the result block of
+    a pass with per-vector outputs: on a clean batch, on batches with a damaged header, a damaged section, a
+    section of an illegal kind - and again on the clean batch afterwards (the failure mark of an earlier pass
+    must not stick to the workspace)."""
+    rng = np.random.default_rng(5)
+    good = [oracle.encode_all(oracle.U32, rng.integers(0, 9, size=int(rng.integers(1, 3000))).astype(np.uint32))
+            for _ in range(40)]
+
+    def blocks(vecs):
+        dev = cv.EncodedBatch.from_vectors("u32", vecs).to_device()
+        r_total = dev.filter_count_async(3).cpu().numpy().copy()
+        pv = torch.empty(dev.n_vectors, dtype=torch.int64, device=dev.device)
+        st = torch.empty(dev.n_vectors, dtype=torch.int32, device=dev.device)
+        r_full = dev.filter_count_async(3, pv, st).cpu().numpy().copy()
+        r_again = dev.filter_count_async(3).cpu().numpy().copy()
+        d_total = dev.decode_async(torch.zeros(dev.n_sections * 256, dtype=torch.int32, device=dev.device)).cpu().numpy().copy()
+        d_full = dev.decode_async(torch.zeros(dev.n_sections * 256, dtype=torch.int32, device=dev.device), status=st).cpu().numpy().copy()
+        assert np.array_equal(r_total[:3], r_full[:3]) and np.array_equal(r_again[:3], r_full[:3]), (r_total, r_full, r_again)
+        assert np.array_equal(d_total[:3], d_full[:3]), (d_total, d_full)
+        host = dev.download()
+        wtotal, _, wst, _ = oracle.batch_filter_count(oracle.U32, host.blob, host.byte_off, 3)
+        assert int(r_total[0]) == wtotal and int(r_total[1]) == int((np.asarray(wst) != 0).sum())
+        return r_total
+
+    import torch
+    clean = blocks(good)
+    assert clean[1] == 0
+    bad_header = bytearray(good[7]); bad_header[5] = 0x10
+    assert blocks(good[:7] + [bytes(bad_header)] + good[8:])[1] == 1
+    big = max(range(len(good)), key=lambda i: len(good[i]))
+    _, nb = oracle.section_parse(oracle.U32, good[big][16:])
+    bad_octet = bytearray(good[big]); bad_octet[16 + nb + 3 + 1] = 0xf0      # second section: an octet of 16 nibbles
+    assert blocks(good[:big] + [bytes(bad_octet)] + good[big + 1:])[1] == 1
+    xor = bytearray(oracle.encode_all(oracle.F32, (np.arange(600) / 1.3).astype(np.float32))); xor[5] = 0x11
+    assert blocks(good[:3] + [bytes(xor)] + good[3:])[1] == 1              # Xor sections in a u32 vector
+    short = good[11][:len(good[11]) - 1] if len(good[11]) > 40 else good[12][:len(good[12]) - 1]
+    assert blocks(good[:20] + [short] + good[20:])[1] == 1                 # truncated body
+    again = blocks(good)
+    assert np.array_equal(again[:3], clean[:3])
+
+
 def test_damaged_element_count_is_bounded_by_the_bytes(cv, oracle):
     """A header whose num_elements (src/vector.rs:165) claims far more sections than the vector's bytes
     could hold must not size any buffer: the vector gets one slot more than its bytes allow, reports a
