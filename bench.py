@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--prewarm", type=int, default=300,
                     help="untimed filter passes during set-up, before the warmup steps: the GPU needs a few "
                          "hundred launches to reach its steady clock (0.207 -> 0.195 ms per section kernel)")
-    ap.add_argument("--event-steps", type=int, default=32,
+    ap.add_argument("--event-steps", type=int, default=16,
                     help="timed steps whose kernels are bracketed with HIP events for the roofline figure")
     ap.add_argument("--dist-single", action="store_true",
                     help="take the multi-rank code path (process group, all-reduce) with a single rank; for testing")

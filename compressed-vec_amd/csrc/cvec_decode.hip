@@ -297,7 +297,7 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_TINY ? 4 : (PI
                                                           uint8_t *__restrict__ masks, void *__restrict__ out_,
                                                           const uint64_t *__restrict__ tag, uint64_t cookie,
                                                           const uint8_t *__restrict__ gate, uint32_t *__restrict__ work,
-                                                          uint32_t n_groups, uint32_t epoch) {
+                                                          uint32_t n_groups, uint32_t epoch, uint32_t keep_cached) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared<PIECES> sm;
     // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
@@ -387,10 +387,20 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_TINY ? 4 : (PI
         const uint32_t span_bytes = c.nch * 16u;
 #endif
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(bytes + c.gb), 0, (int)span_bytes, 0x00020000);
+        // Cache policy of the span loads (a uniform branch: the policy is an immediate of the instruction).
+        // Non-temporal for blobs far beyond the 256 MiB last-level cache: every byte is read once per pass, and
+        // without the hint the same loads take 13 % longer (0.217 against 0.191 ms per GiB of incompressible
+        // f32).  Default policy for count and mask passes over smaller blobs: a batch that is queried again and
+        // again then stays in that cache from one pass to the next, index pass included (dense u32, 0.2 GB: 0.187
+        // -> 0.170 ms per pass; 0.6 GB of f32: 0.184 -> 0.181).  Decode passes keep the hint: their output would
+        // push the blob out anyway, and with the default policy dense u32 decodes a third slower.
+        if (keep_cached) {
 #pragma unroll
-        for (int i = 0; i < PIECES; i++)
-            // nt: every byte is read once; without it the same loads take 13 % longer (0.217 against 0.191 ms per GiB)
-            R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 2);
+            for (int i = 0; i < PIECES; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 2);
+        }
     };
 
 #pragma unroll
@@ -789,6 +799,10 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         const uint32_t nwg = (uint32_t)((nwaves + SEC_WAVES - 1) / SEC_WAVES);
         SinkArgs sa2 = sa;
         sa2._pad = (uint32_t)ablate; // always 0 in the product build
+        // blobs up to 640 MiB are worth keeping in the last-level cache between passes (see issue_loads)
+        uint32_t keep_cached = mode != MODE_DECODE && n_bytes != 0 && n_bytes <= (640ull << 20) ? 1u : 0u;
+        if (ablate == 6) keep_cached = 1;
+        if (ablate == 7) keep_cached = 0;
         // the predicate list padded to its bucket with copies of the first value
         PredArgs pb = pa;
         uint32_t bucket = 1;
@@ -796,7 +810,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
 #define CVEC_LAUNCH_SEC_P(M, N, P)                                                                                  \
     k_sections<ETYPE, M, N, P><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
-                                                                tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch)
+                                                                tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
         /* (the conditional constants keep the shapes a mode never takes from being instantiated) */                \

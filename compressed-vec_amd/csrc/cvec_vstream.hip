@@ -85,7 +85,8 @@ __global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
     const uint8_t *__restrict__ bytes, uint32_t padded_bytes, const uint64_t *__restrict__ byte_off,
     const uint64_t *__restrict__ sec_base, uint32_t n, uint32_t per, PredArgs pa, SinkArgs sa,
     uint64_t *__restrict__ per_vec, int32_t *__restrict__ status_out, uint8_t *__restrict__ masks, void *__restrict__ out_,
-    uint32_t out_bytes, uint32_t *__restrict__ nvalid, uint64_t *__restrict__ result, uint64_t *__restrict__ tag) {
+    uint32_t out_bytes, uint32_t *__restrict__ nvalid, uint64_t *__restrict__ result, uint64_t *__restrict__ tag,
+    uint32_t keep_cached) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
     using S = VsShape<SP>;
@@ -156,13 +157,17 @@ __global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
     static_assert(S::SLOT_PIECES >= 64 && (S::SLOT_PIECES - 64) % 8 == 0 && 16 + TAILS == S::LOADS, "piece mapping");
     const uint32_t lane16 = 16u * (uint32_t)lane;
     const uint32_t tail_src = ((uint32_t)lane >> 3) << 4;      // bpermute address of the quad that owns this lane's tail window (of 8)
-    auto issue_loads = [&](uint32_t base, uint32_t pl) { // pieces [f0, f1) of plan word pl, for every quad's window
+    // (the cache policy is an immediate of the load instruction: non-temporal for blobs far beyond the last-level
+    // cache, where every byte is read once per pass; the default policy for the count and mask passes over smaller
+    // blobs, which then stay cached from one pass over a resident batch to the next)
+    auto issue_loads_p = [&](auto policy, uint32_t base, uint32_t pl) { // pieces [f0, f1) of plan word pl, for every quad's window
+        constexpr int POL = decltype(policy)::value;
 #pragma unroll
         for (int wi = 0; wi < TILE; wi++) {
             const uint32_t ba = (uint32_t)__builtin_amdgcn_readlane((int)base, 4 * wi);
             const uint32_t ff = (uint32_t)__builtin_amdgcn_readlane((int)pl, 4 * wi);
             const bool mine = (uint32_t)lane >= (ff & 0xffu) && (uint32_t)lane < ((ff >> 8) & 0xffu);
-            R[wi] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, mine ? ba + lane16 : 0xffffff00u, 0, 2 /* nt: read once */);
+            R[wi] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, mine ? ba + lane16 : 0xffffff00u, 0, POL);
         }
 #pragma unroll
         for (int t = 0; t < TAILS; t++) {
@@ -172,8 +177,12 @@ __global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
             const uint32_t ff = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pl);
             const uint32_t pc = 64u + 8u * (uint32_t)(t >> 1) + ((uint32_t)lane & 7u);
             const bool mine = pc >= (ff & 0xffu) && pc < ((ff >> 8) & 0xffu);
-            R[TILE + t] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, mine ? ba + 16u * pc : 0xffffff00u, 0, 2);
+            R[TILE + t] = __builtin_amdgcn_raw_buffer_load_b128(brsrc, mine ? ba + 16u * pc : 0xffffff00u, 0, POL);
         }
+    };
+    auto issue_loads = [&](uint32_t base, uint32_t pl) {
+        if (keep_cached) issue_loads_p(std::integral_constant<int, 0>(), base, pl);
+        else issue_loads_p(std::integral_constant<int, 2>(), base, pl);
     };
     // staging registers -> slots: only the pieces that were requested (the rest of a slot keeps its bytes)
     auto write_slots = [&](uint32_t pl) {
@@ -583,15 +592,18 @@ static void launch_vstream_t(int mode, const cvec_dbatch_view &b, const PredArgs
     while (bucket < pb.count) bucket *= 2;
     for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
     SinkArgs sb = sa;
+    uint32_t keep_cached = mode != MODE_DECODE && b.n_bytes <= (640ull << 20) ? 1u : 0u; // as in launch_sections
 #ifdef CVEC_PROBES
     static const int ablate = [] { const char *e = getenv("CVEC_ABLATE"); return e ? atoi(e) : 0; }();
     sb._pad = (uint32_t)ablate; // probe build: 1 = everything but the octet loop
+    if (ablate == 6) keep_cached = 1;
+    if (ablate == 7) keep_cached = 0;
     (void)hipMemsetAsync(tag + 8, 0, 64, stream);
 #endif
 #define CVEC_VS(M, N)                                                                                                      \
     k_vstream<ETYPE, M, N, VS_PIECES_LARGE><<<nwg, SEC_THREADS, 0, stream>>>(b.d_bytes, padded, b.d_byte_off, b.d_sec_base, n, \
                                                                             per, pb, sb, d_per_vector, d_status, d_masks,  \
-                                                                            d_out, out_bytes, nvalid, d_result, tag)
+                                                                            d_out, out_bytes, nvalid, d_result, tag, keep_cached)
 #define CVEC_VS_BUCKET(M)                                                                                                  \
     switch (bucket) {                                                                                                      \
     case 1: CVEC_VS(M, 1); break;                                                                                          \
