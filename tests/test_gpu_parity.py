@@ -487,6 +487,61 @@ def test_total_only_pass_equals_the_per_vector_pass(cv, oracle):
     assert np.array_equal(again[:3], clean[:3])
 
 
+@pytest.mark.parametrize("tname", ["u32", "f32", "u64"])
+def test_big_ragged_batch_with_damage_vs_oracle(cv, oracle, tname):
+    """More than 65536 sections: the section kernel hands out its slot ranges on demand (its waves draw them from
+    counters and move on to other counters at the end).  40000 ragged vectors, every tenth one with damaged bytes:
+    statuses, per-vector counts, masks and decoded values of every vector must equal the oracle's, the total-only
+    pass must equal the per-vector pass, and a second pass must give the same again."""
+    rng = np.random.default_rng(404)
+    et = ET[tname]
+    uniq = []
+    for i in range(1500):
+        flat, off = _random_vectors(rng, tname, 1, max_len=int(rng.integers(200, 2500)))
+        vec = bytearray(oracle.encode_all(et, flat))
+        if i % 10 == 3 and len(vec) > 24:
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(0, len(vec))) if rng.random() < 0.5 else 16 + int(rng.integers(0, min(12, len(vec) - 16)))
+                vec[at] = int(rng.integers(0, 256))
+        uniq.append(bytes(vec))
+    pick = rng.integers(0, len(uniq), size=40000)
+    host = cv.EncodedBatch.from_vectors(tname, [uniq[i] for i in pick])
+    dev = host.to_device()
+    assert dev.n_sections > 65536
+    pred = NPD[tname](0)
+    # the oracle once per distinct vector
+    want = {}
+    for i in set(int(x) for x in pick):
+        blob = np.frombuffer(uniq[i], dtype=np.uint8)
+        bo = np.array([0, blob.size], dtype=np.uint64)
+        wtotal, wper, wst, _ = oracle.batch_filter_count(et, blob, bo, pred)
+        want[i] = (int(wper[0]), int(wst[0]))
+    sb = dev.d_sec_base.cpu().numpy().view(np.uint64)
+    for rep in range(2):
+        total, per, st, masks = dev.filter_count(pred, per_vector=True, return_status=True, return_masks=True)
+        assert int(total) == int(np.asarray(per).sum())
+        wper = np.array([want[int(i)][0] for i in pick], dtype=np.uint64)
+        wst = np.array([want[int(i)][1] for i in pick], dtype=np.int32)
+        ok = np.asarray(st) != 100            # (a damaged element count is reported as a section-count mismatch)
+        assert np.array_equal(np.asarray(st)[ok], wst[ok]) and np.array_equal(np.asarray(per)[ok], wper[ok])
+        assert int((np.asarray(st) != 0).sum()) > 1000
+        r = dev.filter_count_async(pred).cpu().numpy()
+        assert int(r[0]) == int(total) and int(r[1]) == int((np.asarray(st) != 0).sum())
+    # masks and decoded values of a sample of healthy vectors
+    dec, doff, dst = dev.decode(return_status=True)
+    assert np.array_equal(np.asarray(dst)[ok], wst[ok])
+    for v in rng.integers(0, len(pick), size=300):
+        v = int(v)
+        if st[v] != 0:
+            continue
+        blob = np.frombuffer(uniq[int(pick[v])], dtype=np.uint8)
+        _, wm = oracle.filter_count(et, blob, pred, return_masks=True)
+        assert np.array_equal(np.asarray(masks[32 * int(sb[v]):32 * int(sb[v + 1])]), np.asarray(wm, dtype=np.uint8).reshape(-1)), v
+        wdec, _, rc = oracle.batch_decode(et, blob, np.array([0, blob.size], dtype=np.uint64), np.array([0, 256 * int(sb[v + 1] - sb[v])], dtype=np.uint64))
+        a, b = int(doff[v]), int(doff[v + 1])
+        assert rc == 0 and np.array_equal(_bits(np.asarray(dec[a:b])), _bits(np.asarray(wdec)))
+
+
 def test_damaged_element_count_is_bounded_by_the_bytes(cv, oracle):
     """A header whose num_elements (src/vector.rs:165) claims far more sections than the vector's bytes
     could hold must not size any buffer: the vector gets one slot more than its bytes allow, reports a
