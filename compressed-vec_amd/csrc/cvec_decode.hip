@@ -546,7 +546,13 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_TINY ? 4 : (PI
         } else if (cur.n != 0) {
 #endif
             uint32_t ooff;
+#ifdef CVEC_PROBES
+            // probe build: 2 = the decode pass with every store aimed past its descriptor (issued, then dropped)
+            const out_rsrc_t orsrc = sa._pad == 2 ? chunk_out_rsrc<W, MODE_FILTER>(out_, s_cur + sec, lane, ooff)
+                                                  : chunk_out_rsrc<W, MODE>(out_, s_cur + sec, lane, ooff);
+#else
             const out_rsrc_t orsrc = chunk_out_rsrc<W, MODE>(out_, s_cur + sec, lane, ooff);
+#endif
             const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES)>(
                 data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff);
             if constexpr (W == 4) {
