@@ -5,8 +5,8 @@
 //   k_index     one lane per vector walks its section headers (the chain of
 //               FixedSectIterator::next, reference src/section.rs:864-876) and writes one
 //               descriptor per 256-element section slot.
-//   k_sections  persistent, wave-autonomous: every wave owns a contiguous range of section slots
-//               and an 18 KiB LDS region, streams 16 sections at a time into it (bounds-checked
+//   k_sections  persistent, wave-autonomous: every wave draws ranges of section slots from counters
+//               in the workspace, owns an 18 KiB LDS region, streams 16 sections at a time into it (bounds-checked
 //               16-byte buffer loads -> registers -> LDS, the next chunk prefetched into registers
 //               while the current one is processed) and runs the 32 octet steps of all 16 sections
 //               at once: a quad of lanes per section walks the octet headers (the chain inside
@@ -14,7 +14,8 @@
 //               its two elements of every octet straight out of the bitstream, keeps the XOR state
 //               in registers and either compares (filter) or stores.  No barriers, no octet table.
 //   k_finalize  one lane per vector folds its sections' results in order, so a failing section
-//               ends that vector exactly where the reference's iteration would stop.
+//               ends that vector exactly where the reference's iteration would stop; a pass that
+//               wants the total alone and met no failure takes the section kernel's sums instead.
 #include <stdlib.h>
 #include <string.h>
 
@@ -281,14 +282,15 @@ hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_
 #define SEC_STAMP(i) do { } while (0)
 #endif
 
-// k_sections: every wave is on its own.  A wave owns a contiguous range of section slots and an
-// 18 KiB staging region in LDS, and loops over chunks of up to 16 sections.  Per chunk: the bytes
+// k_sections: every wave is on its own.  A wave works through ranges of section slots (its first one fixed,
+// the others drawn from the workspace's counters) with an 18, 12 or 6 KiB staging region in LDS, and loops
+// over chunks of up to 16 sections.  Per chunk: the bytes
 // prefetched into registers during the previous chunk's compute are written to the region; the next
 // chunk is planned from its descriptors and its global loads are issued into those registers (plus
 // the descriptor loads of the chunk after it); then the 16 sections are walked and decoded at once
 // (process_chunk) while the loads fly.  Registers, not a second LDS region, double-buffer the
 // stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
-// No barriers and no cross-wave traffic.
+// No barriers; the only traffic between waves are the range counters.
 template <int ETYPE, int MODE, int NPRED, int PIECES>
 __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_TINY ? 4 : (PIECES <= REGION_PIECES_SMALL ? 3 : 2)) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
