@@ -777,7 +777,12 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 4) tiny = false;
         if (tiny) small = false;
         const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
-        const uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
+        uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
+#ifdef CVEC_PROBES
+        // probe build: a cap on the waves of a launch, so that small test batches run with many ranges per wave
+        static const int max_waves_env = [] { const char *e = getenv("CVEC_MAX_WAVES"); return e ? atoi(e) : 0; }();
+        if (max_waves_env > 0) nwaves_max = (uint64_t)max_waves_env;
+#endif
         // `work` (a counter that is zero when the kernel starts; not for gated passes, whose waves skip ahead in
         // their own ranges): ranges an eighth of a wave's even share, handed out on demand (see k_sections).
         // Without it every wave gets one range of that even share.
