@@ -22,7 +22,6 @@ constexpr int TILE = 16; // sections per chunk: one per quad of lanes
 // 0.159 ms per GiB); 16 incompressible f32 sections do not fit 12 KiB and lose more lanes than that gains.
 constexpr int REGION_PIECES = 18;
 constexpr int REGION_PIECES_SMALL = 12;
-constexpr int REGION_PIECES_TINY = 6; // 6 KiB regions at four workgroups per CU: sections of a few hundred bytes
 
 // The last 64 bytes of a region stay zero: sections without octets (Null, Const, skipped slots) run
 // the octet loop over them (32 empty octets), which keeps the loop free of per-kind masking.
