@@ -393,8 +393,8 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
         // Non-temporal for blobs far beyond the 256 MiB last-level cache: every byte is read once per pass, and
         // without the hint the same loads take 13 % longer (0.217 against 0.191 ms per GiB of incompressible
         // f32).  Default policy for count and mask passes over smaller blobs: a batch that is queried again and
-        // again then stays in that cache from one pass to the next, index pass included (dense u32, 0.2 GB: 0.187
-        // -> 0.170 ms per pass; 0.6 GB of f32: 0.184 -> 0.181).  Decode passes keep the hint: their output would
+        // again then stays in that cache from one pass to the next, index pass included (dense u32, 0.2 GB: 0.203
+        // -> 0.186 ms per pass; 0.6 GB of f32: 0.189 -> 0.187).  Decode passes keep the hint: their output would
         // push the blob out anyway, and with the default policy dense u32 decodes a third slower.
         if (keep_cached) {
 #pragma unroll
