@@ -322,6 +322,12 @@ def main():
                 del values, batch
                 torch.cuda.empty_cache()
                 out["extra"]["configs"] = config_table(torch, cv, N)
+                # every configuration's count against a direct count on its values: a false one means a kernel
+                # gave wrong results at full size, whatever its throughput says
+                out["extra"]["all_configs_exact"] = all(r["filter_count_equals_direct_count"] for r in out["extra"]["configs"])
+                if not out["extra"]["all_configs_exact"]:
+                    print("bench.py: a configuration's filter count differs from the direct count (see extra.configs)",
+                          file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
