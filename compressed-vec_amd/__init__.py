@@ -10,10 +10,11 @@ from . import stream
 from . import hostpath
 from . import histogram
 from .hostpath import decode_host, encode_host, filter_count_host
+from .series import SeriesAppender
 from .sink import AddConstSink, Section256Sink, VecSink
 from .vector import (VectorAppender, VectorF32XorAppender, VectorReader, VectorU32Appender, VectorU64Appender)
 
-__all__ = ["hostpath", "stream", "histogram", "decode_host", "encode_host", "filter_count_host", "MultiVectorFilter", "FilteredColumn", "multi_filter", "multi_filter_count", "CodingError", "U32", "U64", "F32", "DeviceBatch", "EncodedBatch", "encode_batch", "encode_device",
+__all__ = ["SeriesAppender", "hostpath", "stream", "histogram", "decode_host", "encode_host", "filter_count_host", "MultiVectorFilter", "FilteredColumn", "multi_filter", "multi_filter_count", "CodingError", "U32", "U64", "F32", "DeviceBatch", "EncodedBatch", "encode_batch", "encode_device",
            "EqualsSink", "OneOfSink", "VectorFilter", "count_hits", "match_positions", "AddConstSink",
            "Section256Sink", "VecSink", "VectorAppender", "VectorF32XorAppender", "VectorReader",
            "VectorU32Appender", "VectorU64Appender", "etype_of", "make_pred", "lib", "LIB_PATH"]

@@ -105,6 +105,17 @@ SIGNATURES = {
     "cvec_appender_finish": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_uint64)]),
     "cvec_appender_reader": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cvec_series_appender_new": (C.c_int32, [C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "cvec_series_appender_free": (None, [C.c_void_p]),
+    "cvec_series_appender_reset": (C.c_int32, [C.c_void_p]),
+    "cvec_series_appender_append_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cvec_series_appender_append_nulls_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cvec_series_appender_seal": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]),
+    "cvec_series_appender_emit_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cvec_series_appender_unseal": (C.c_int32, [C.c_void_p]),
+    "cvec_series_appender_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_uint64)]),
     "cvec_error_detail_dev": (C.c_int32, [C.POINTER(DBatchView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cvec_multi_workspace_bytes": (C.c_size_t, [C.c_uint64]),
     "cvec_multi_filter_count_dev": (C.c_int32, [C.POINTER(MaskColumn), C.c_uint32, C.c_uint64, C.c_void_p,

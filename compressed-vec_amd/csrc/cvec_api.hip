@@ -87,6 +87,10 @@ static cvec_status hip_fail(hipError_t e, const char *what) {
     snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s", what, hipGetErrorString(e));
     return CVEC_ERR_HIP;
 }
+namespace cvec {
+// for the other translation units: keeps the message that cvec_last_hip_error() returns
+cvec_status record_hip_error(hipError_t e, const char *what) { return hip_fail(e, what); }
+} // namespace cvec
 #define HIP_TRY(expr)                                   \
     do {                                                \
         hipError_t e__ = (expr);                        \

@@ -1,0 +1,531 @@
+// cvec_series.hip — one VectorAppender<T, W> (reference src/vector.rs:207-379) per series, many series at once,
+// resident in HBM.
+//
+// A scrape hands every series a few new values.  Per series the reference keeps an open section of up to 255 raw
+// values (`vect_buf`, src/vector.rs:210, :300-307) and the encoded bytes of the sections that are complete
+// (`write_buf`).  Here both live on the device for all n series of the handle:
+//   stage[n][256], fill[n]   the open sections (raw values) and how many values each holds
+//   len[n], nulls[n]         elements appended (nulls included) and explicit null sections (src/vector.rs:321-327)
+//   segments                 every append call that completes sections encodes exactly those sections, for all
+//                            series at once, with the batch encoder; the result (one short vector per series, header
+//                            included, empty where nothing completed) is kept as a segment at its exact size
+// seal() encodes what finish() adds (the open section padded with zeros and the null sections up to
+// total_num_rows, src/vector.rs:344-359) as a last segment and computes the byte offsets of the final vectors;
+// emit() writes, per series, one header (element and null-section counts, src/vector.rs:160-169) followed by the
+// section bytes of all segments in order.  Sections are independent of their neighbours, so the bytes equal the
+// reference appender's for the same sequence of calls.
+#include <new>
+#include <vector>
+
+#include "cvec_device.hpp"
+
+namespace cvec {
+uint64_t scan_scratch_words(uint64_t n);
+hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *d_scratch, hipStream_t stream);
+size_t encode_workspace_bytes(uint64_t n_vectors, uint64_t n_elements_total);
+hipError_t launch_encode(int32_t etype, const void *d_values, const uint64_t *d_elem_off, uint64_t n_vectors,
+                         uint64_t n_elements_total, uint8_t *d_bytes, size_t bytes_cap, uint64_t *d_byte_off,
+                         uint64_t *d_sec_base, uint64_t *d_result, void *d_workspace, size_t workspace_bytes,
+                         hipStream_t stream);
+cvec_status record_hip_error(hipError_t e, const char *what);
+} // namespace cvec
+
+using namespace cvec;
+
+namespace {
+
+constexpr uint32_t SER_THREADS = 256;
+constexpr uint32_t SER_WAVES = SER_THREADS / 64;
+
+struct Buf { // grow-only device buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    ~Buf() { if (p) (void)hipFree(p); }
+    hipError_t need(size_t n) {
+        n = n ? n : 16;
+        if (p && cap >= n) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct Segment {
+    uint8_t *bytes = nullptr;
+    uint64_t *off = nullptr; // n + 1
+    uint64_t n_bytes = 0;
+};
+
+// ---- kernels ---------------------------------------------------------------------------------------------
+
+// One lane per series: how many values arrive and how many of open + new leave as complete sections.
+__global__ void k_ser_plan(uint64_t n, const uint64_t *__restrict__ elem_off, uint64_t per_vector, int nulls_mode,
+                           const uint32_t *__restrict__ fill, uint64_t *__restrict__ len, uint32_t *__restrict__ nulls,
+                           uint64_t *__restrict__ flush_cnt) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t c = elem_off ? elem_off[v + 1] - elem_off[v] : per_vector;
+    const uint32_t f = fill[v];
+    if (nulls_mode) {
+        // src/vector.rs:311-335: zeros fill the open section first; whole runs of 256 behind an empty open
+        // section are explicit null sections
+        uint64_t left = c;
+        uint32_t open = f;
+        if (left && open) {
+            const uint64_t room = FIXED_LEN - open;
+            const uint64_t fillup = left < room ? left : room;
+            open = (uint32_t)((open + fillup) % FIXED_LEN);
+            left -= fillup;
+        }
+        if (open == 0) nulls[v] += (uint32_t)(left / FIXED_LEN);
+    }
+    len[v] += c;
+    flush_cnt[v] = ((uint64_t)f + c) / FIXED_LEN * FIXED_LEN;
+}
+
+// One wave per series: the first out_off[v+1] - out_off[v] elements of (open section ++ new values ++ zeros).
+template <class U>
+__global__ __launch_bounds__(SER_THREADS) void k_ser_flush(uint64_t n, const U *__restrict__ values,
+                                                           const uint64_t *__restrict__ elem_off, uint64_t per_vector,
+                                                           const U *__restrict__ stage, const uint32_t *__restrict__ fill,
+                                                           const uint64_t *__restrict__ out_off, U *__restrict__ out) {
+    const uint64_t v = (uint64_t)blockIdx.x * SER_WAVES + threadIdx.x / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const uint64_t o0 = out_off[v], cnt = out_off[v + 1] - o0;
+    if (cnt == 0) return;
+    const uint32_t f = fill[v];
+    uint64_t base = 0, c = 0;
+    if (values) {
+        base = elem_off ? elem_off[v] : v * per_vector;
+        c = elem_off ? elem_off[v + 1] - base : per_vector;
+    }
+    for (uint64_t i = lane; i < cnt; i += 64) {
+        U x = 0;
+        if (i < f) x = stage[v * FIXED_LEN + i];
+        else if (i - f < c) x = values[base + (i - f)];
+        out[o0 + i] = x;
+    }
+}
+
+// One wave per series: what stays behind in the open section after the complete sections left.
+template <class U>
+__global__ __launch_bounds__(SER_THREADS) void k_ser_stage(uint64_t n, const U *__restrict__ values,
+                                                           const uint64_t *__restrict__ elem_off, uint64_t per_vector,
+                                                           U *__restrict__ stage, uint32_t *__restrict__ fill) {
+    const uint64_t v = (uint64_t)blockIdx.x * SER_WAVES + threadIdx.x / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const uint64_t base = elem_off ? elem_off[v] : v * per_vector;
+    const uint64_t c = elem_off ? elem_off[v + 1] - base : per_vector;
+    const uint32_t f = fill[v];
+    const uint64_t tot = f + c, closed = tot / FIXED_LEN * FIXED_LEN;
+    const uint32_t nf = (uint32_t)(tot - closed);
+    U *row = stage + v * FIXED_LEN;
+    if (closed == 0) {
+        for (uint64_t i = f + lane; i < tot; i += 64) row[i] = values ? values[base + (i - f)] : (U)0;
+    } else {
+        // closed >= 256 > f: everything that stays comes from the new values
+        for (uint32_t i = lane; i < nf; i += 64) row[i] = values ? values[base + (closed - f) + i] : (U)0;
+    }
+    if (lane == 0 && c) fill[v] = nf;
+}
+
+__global__ void k_ser_max_len(uint64_t n, const uint64_t *__restrict__ len, unsigned long long *__restrict__ out) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = v < n ? len[v] : 0;
+    for (int d = 32; d; d >>= 1) {
+        const uint64_t y = __shfl_xor(x, d);
+        x = y > x ? y : x;
+    }
+    if ((threadIdx.x & 63) == 0 && x) atomicMax(out, (unsigned long long)x);
+}
+
+// One lane per series: elements of the closing segment (open section + zeros up to total_rows).
+__global__ void k_ser_tail_plan(uint64_t n, uint64_t total_rows, const uint64_t *__restrict__ len,
+                                const uint32_t *__restrict__ fill, uint64_t *__restrict__ tail_cnt) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t flushed = len[v] - fill[v];
+    tail_cnt[v] = total_rows >= flushed ? total_rows - flushed : 0;
+}
+
+// One lane per series: size of the final vector and its number of sections.
+__global__ void k_ser_sizes(uint64_t n, int reader, uint64_t total_rows, const uint64_t *__restrict__ len,
+                            const uint32_t *__restrict__ fill, const uint64_t *const *__restrict__ seg_off, uint32_t n_seg,
+                            uint64_t *__restrict__ out_size, uint64_t *__restrict__ out_nsec) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    uint64_t size = HEADER_BYTES;
+    for (uint32_t s = 0; s < n_seg; s++) {
+        const uint64_t *o = seg_off[s];
+        size += o[v + 1] - o[v] - HEADER_BYTES;
+    }
+    const uint64_t elems = reader ? len[v] - fill[v] : total_rows;
+    out_size[v] = size;
+    out_nsec[v] = (elems + FIXED_LEN - 1) / FIXED_LEN;
+}
+
+// One wave per series: header, then the section bytes of every segment in order.
+__global__ __launch_bounds__(SER_THREADS) void k_ser_gather(uint64_t n, int etype, int reader, uint64_t total_rows,
+                                                            const uint64_t *__restrict__ len, const uint32_t *__restrict__ fill,
+                                                            const uint32_t *__restrict__ nulls,
+                                                            const uint64_t *const *__restrict__ seg_off,
+                                                            const uint8_t *const *__restrict__ seg_bytes, uint32_t n_seg,
+                                                            const uint64_t *__restrict__ byte_off, uint8_t *__restrict__ bytes) {
+    const uint64_t v = (uint64_t)blockIdx.x * SER_WAVES + threadIdx.x / 64;
+    const uint32_t lane = threadIdx.x & 63;
+    if (v >= n) return;
+    const uint64_t start = byte_off[v], end = byte_off[v + 1];
+    uint8_t *dst = bytes + start;
+    if (lane < HEADER_BYTES) {
+        const uint64_t l = len[v];
+        const uint64_t elems = reader ? l - fill[v] : total_rows;
+        uint32_t nn = nulls[v];
+        if (!reader) {
+            // src/vector.rs:352-359: the open section is rounded out, then null sections up to total_rows
+            const uint64_t padded = (l + FIXED_LEN - 1) / FIXED_LEN * FIXED_LEN;
+            if (total_rows > padded) nn += (uint32_t)((total_rows - padded + FIXED_LEN - 1) / FIXED_LEN);
+        }
+        const uint32_t num_bytes = (uint32_t)(end - start - 4); // BinaryVector.num_bytes (src/vector.rs:54, :139)
+        uint8_t b = 0;
+        if (lane < 4) b = (uint8_t)(num_bytes >> (8 * lane));
+        else if (lane == 4) b = 0x10;                           // VectorType::FixedSection256
+        else if (lane == 5) b = (uint8_t)etype;                 // VectorSubType
+        else if (lane >= 8 && lane < 12) b = (uint8_t)((uint32_t)elems >> (8 * (lane - 8)));
+        else if (lane == 12) b = (uint8_t)(nn & 0xff);          // FixedSectStats.num_null_sections (src/vector.rs:163-186)
+        else if (lane == 13) b = (uint8_t)((nn >> 8) & 0xff);
+        dst[lane] = b;
+    }
+    dst += HEADER_BYTES;
+    for (uint32_t s = 0; s < n_seg; s++) {
+        const uint64_t *o = seg_off[s];
+        const uint64_t s0 = o[v] + HEADER_BYTES, s1 = o[v + 1];
+        const uint8_t *src = seg_bytes[s] + s0;
+        const uint64_t m = s1 - s0;
+        for (uint64_t i = lane; i < m; i += 64) dst[i] = src[i];
+        dst += m;
+    }
+}
+
+inline uint32_t lane_blocks(uint64_t n) { return (uint32_t)((n + SER_THREADS - 1) / SER_THREADS); }
+inline uint32_t wave_blocks(uint64_t n) { return (uint32_t)((n + SER_WAVES - 1) / SER_WAVES); }
+
+} // namespace
+
+struct cvec_series_appender {
+    int32_t etype = 0;
+    int device = 0;
+    uint64_t n = 0;
+    uint32_t width = 4;
+    Buf stage, fill, len, nulls;         // per series state
+    Buf cnt, off, scan_tmp, vals;        // per call: elements leaving per series, their scan, the values
+    Buf enc_bytes, enc_off, enc_sec, enc_res, enc_ws;
+    Buf out_size, out_off, out_nsec, out_sec, tab_off, tab_bytes, maxlen;
+    std::vector<Segment> segs;
+    Segment tail;
+    int sealed = 0;                      // 0 open, 1 sealed for finish, 2 sealed for reader
+    uint64_t sealed_rows = 0, sealed_bytes = 0, sealed_sections = 0;
+    uint64_t resident_bytes = 0;
+
+    void drop(Segment &s) {
+        if (s.bytes) (void)hipFree(s.bytes);
+        if (s.off) (void)hipFree(s.off);
+        s = Segment();
+    }
+    ~cvec_series_appender() {
+        for (Segment &s : segs) drop(s);
+        drop(tail);
+    }
+};
+
+#define SER_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (expr);                                             \
+        if (e__ != hipSuccess) return record_hip_error(e__, #expr);          \
+    } while (0)
+
+namespace {
+
+struct DeviceScope { // the handle's device is current inside every call, the caller's afterwards
+    int prev = -1;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+cvec_status clear_state(cvec_series_appender *a, hipStream_t st) {
+    SER_TRY(hipMemsetAsync(a->fill.p, 0, a->n * 4 + 16, st));
+    SER_TRY(hipMemsetAsync(a->len.p, 0, a->n * 8 + 16, st));
+    SER_TRY(hipMemsetAsync(a->nulls.p, 0, a->n * 4 + 16, st));
+    SER_TRY(hipStreamSynchronize(st));
+    for (Segment &s : a->segs) a->drop(s);
+    a->segs.clear();
+    a->drop(a->tail);
+    a->sealed = 0;
+    a->resident_bytes = 0;
+    return CVEC_OK;
+}
+
+// Encodes `total` values (series v owns [off[v], off[v+1])) and keeps the result at its exact size.
+cvec_status encode_segment(cvec_series_appender *a, const void *vals, const uint64_t *off, uint64_t total, Segment *seg,
+                           hipStream_t st) {
+    const uint64_t n = a->n;
+    const size_t cap = cvec_max_encoded_bytes(a->etype, n, total);
+    const size_t wsb = encode_workspace_bytes(n, total);
+    SER_TRY(a->enc_bytes.need(cap + 256));
+    SER_TRY(a->enc_off.need((n + 1) * 8));
+    SER_TRY(a->enc_sec.need((n + 1) * 8));
+    SER_TRY(a->enc_res.need(CVEC_RESULT_WORDS * 8));
+    SER_TRY(a->enc_ws.need(wsb));
+    SER_TRY(launch_encode(a->etype, vals, off, n, total, a->enc_bytes.as<uint8_t>(), cap, a->enc_off.as<uint64_t>(),
+                          a->enc_sec.as<uint64_t>(), a->enc_res.as<uint64_t>(), a->enc_ws.p, wsb, st));
+    uint64_t n_bytes = 0;
+    SER_TRY(hipMemcpyAsync(&n_bytes, a->enc_res.p, 8, hipMemcpyDeviceToHost, st));
+    SER_TRY(hipStreamSynchronize(st));
+    if (n_bytes < n * HEADER_BYTES || n_bytes > cap) return CVEC_ERR_HIP;
+    Segment s;
+    SER_TRY(hipMalloc((void **)&s.bytes, n_bytes + 16));
+    hipError_t e = hipMalloc((void **)&s.off, (n + 1) * 8);
+    if (e != hipSuccess) { (void)hipFree(s.bytes); return record_hip_error(e, "hipMalloc(segment offsets)"); }
+    s.n_bytes = n_bytes;
+    e = hipMemcpyAsync(s.bytes, a->enc_bytes.p, n_bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.off, a->enc_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(s.bytes); (void)hipFree(s.off); return record_hip_error(e, "segment copy"); }
+    *seg = s;
+    return CVEC_OK;
+}
+
+template <class U>
+cvec_status append_t(cvec_series_appender *a, const void *d_values, const uint64_t *d_elem_off, uint64_t per_vector,
+                     int nulls_mode, hipStream_t st) {
+    const uint64_t n = a->n;
+    uint64_t *cnt = a->cnt.as<uint64_t>(), *off = a->off.as<uint64_t>();
+    k_ser_plan<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, d_elem_off, per_vector, nulls_mode, a->fill.as<uint32_t>(),
+                                                       a->len.as<uint64_t>(), a->nulls.as<uint32_t>(), cnt);
+    SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
+    uint64_t total = 0;
+    SER_TRY(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
+    SER_TRY(hipStreamSynchronize(st));
+    if (total) {
+        SER_TRY(a->vals.need(total * sizeof(U)));
+        k_ser_flush<U><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, (const U *)d_values, d_elem_off, per_vector,
+                                                               a->stage.as<U>(), a->fill.as<uint32_t>(), off, a->vals.as<U>());
+    }
+    k_ser_stage<U><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, (const U *)d_values, d_elem_off, per_vector, a->stage.as<U>(),
+                                                           a->fill.as<uint32_t>());
+    SER_TRY(hipGetLastError());
+    if (total) {
+        Segment s;
+        cvec_status cs = encode_segment(a, a->vals.p, off, total, &s, st);
+        if (cs) return cs;
+        a->segs.push_back(s);
+        a->resident_bytes += s.n_bytes;
+    } else {
+        SER_TRY(hipStreamSynchronize(st)); // the caller's values may be reused when the call returns
+    }
+    return CVEC_OK;
+}
+
+cvec_status append_any(cvec_series_appender *a, const void *d_values, const uint64_t *d_elem_off, uint64_t per_vector,
+                       int nulls_mode, void *stream) {
+    if (!a) return CVEC_ERR_BAD_ARGUMENT;
+    if (a->sealed) return CVEC_ERR_BAD_ARGUMENT; // between seal and emit the contents are fixed
+    if (a->n == 0) return CVEC_OK;
+    if (!d_elem_off && per_vector == 0) return CVEC_OK;
+    DeviceScope scope(a->device);
+    hipStream_t st = (hipStream_t)stream;
+    return a->width == 8 ? append_t<uint64_t>(a, d_values, d_elem_off, per_vector, nulls_mode, st)
+                         : append_t<uint32_t>(a, d_values, d_elem_off, per_vector, nulls_mode, st);
+}
+
+} // namespace
+
+extern "C" {
+
+cvec_status cvec_series_appender_new(int32_t etype, uint64_t n_series, cvec_series_appender **out) {
+    if (!out || (etype != CVEC_U32 && etype != CVEC_U64 && etype != CVEC_F32)) return CVEC_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (n_series > 0xffffffffull) return CVEC_ERR_BAD_ARGUMENT;
+    cvec_series_appender *a = new (std::nothrow) cvec_series_appender();
+    if (!a) return CVEC_ERR_HIP;
+    a->etype = etype;
+    a->n = n_series;
+    a->width = etype == CVEC_U64 ? 8 : 4;
+    hipError_t e = hipGetDevice(&a->device);
+    const uint64_t n = n_series;
+    if (e == hipSuccess) e = a->stage.need(n * FIXED_LEN * a->width);
+    if (e == hipSuccess) e = a->fill.need(n * 4 + 16);
+    if (e == hipSuccess) e = a->len.need(n * 8 + 16);
+    if (e == hipSuccess) e = a->nulls.need(n * 4 + 16);
+    if (e == hipSuccess) e = a->cnt.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->off.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->scan_tmp.need(scan_scratch_words(n) * 8);
+    if (e == hipSuccess) e = a->out_size.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->out_off.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->out_nsec.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->out_sec.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->maxlen.need(16);
+    if (e != hipSuccess) { delete a; return record_hip_error(e, "cvec_series_appender_new"); }
+    cvec_status cs = clear_state(a, nullptr);
+    if (cs) { delete a; return cs; }
+    *out = a;
+    return CVEC_OK;
+}
+
+void cvec_series_appender_free(cvec_series_appender *a) {
+    if (!a) return;
+    DeviceScope scope(a->device);
+    delete a;
+}
+
+cvec_status cvec_series_appender_reset(cvec_series_appender *a) {
+    if (!a) return CVEC_ERR_BAD_ARGUMENT;
+    DeviceScope scope(a->device);
+    return clear_state(a, nullptr);
+}
+
+cvec_status cvec_series_appender_append_dev(cvec_series_appender *a, const void *d_values, const uint64_t *d_elem_off,
+                                            uint64_t per_series, void *stream) {
+    if (a && !d_values && (d_elem_off || per_series)) return CVEC_ERR_BAD_ARGUMENT;
+    return append_any(a, d_values, d_elem_off, per_series, 0, stream);
+}
+
+cvec_status cvec_series_appender_append_nulls_dev(cvec_series_appender *a, const uint64_t *d_elem_off, uint64_t per_series,
+                                                  void *stream) {
+    return append_any(a, nullptr, d_elem_off, per_series, 1, stream);
+}
+
+cvec_status cvec_series_appender_stats(const cvec_series_appender *a, uint64_t *n_segments, uint64_t *encoded_bytes,
+                                       uint64_t *state_bytes) {
+    if (!a) return CVEC_ERR_BAD_ARGUMENT;
+    if (n_segments) *n_segments = a->segs.size();
+    if (encoded_bytes) *encoded_bytes = a->resident_bytes;
+    if (state_bytes) *state_bytes = a->n * ((uint64_t)FIXED_LEN * a->width + 16) + a->segs.size() * (a->n + 1) * 8;
+    return CVEC_OK;
+}
+
+cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, uint64_t total_num_rows, uint64_t *n_bytes,
+                                      uint64_t *n_sections, uint64_t detail[2], void *stream) {
+    if (!a || a->sealed) return CVEC_ERR_BAD_ARGUMENT;
+    if (detail) detail[0] = detail[1] = 0;
+    DeviceScope scope(a->device);
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t n = a->n;
+    if (!reader) {
+        // src/vector.rs:344-349: more values than rows, or more rows than the header's u32 can say
+        unsigned long long max_len = 0;
+        if (n) {
+            SER_TRY(hipMemsetAsync(a->maxlen.p, 0, 8, st));
+            k_ser_max_len<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, a->len.as<uint64_t>(), a->maxlen.as<unsigned long long>());
+            SER_TRY(hipMemcpyAsync(&max_len, a->maxlen.p, 8, hipMemcpyDeviceToHost, st));
+            SER_TRY(hipStreamSynchronize(st));
+        }
+        if (max_len > total_num_rows) {
+            if (detail) { detail[0] = total_num_rows; detail[1] = max_len; }
+            return CVEC_INVALID_NUM_ROWS;
+        }
+        if (total_num_rows > 0xffffffffull) {
+            if (detail) { detail[0] = total_num_rows; detail[1] = 0xffffffffull; }
+            return CVEC_INVALID_NUM_ROWS;
+        }
+        if (n) {
+            uint64_t *cnt = a->cnt.as<uint64_t>(), *off = a->off.as<uint64_t>();
+            k_ser_tail_plan<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, total_num_rows, a->len.as<uint64_t>(),
+                                                                    a->fill.as<uint32_t>(), cnt);
+            SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
+            uint64_t total = 0;
+            SER_TRY(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
+            SER_TRY(hipStreamSynchronize(st));
+            if (total) {
+                SER_TRY(a->vals.need(total * a->width));
+                if (a->width == 8)
+                    k_ser_flush<uint64_t><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, nullptr, nullptr, 0, a->stage.as<uint64_t>(),
+                                                                                  a->fill.as<uint32_t>(), off, a->vals.as<uint64_t>());
+                else
+                    k_ser_flush<uint32_t><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, nullptr, nullptr, 0, a->stage.as<uint32_t>(),
+                                                                                  a->fill.as<uint32_t>(), off, a->vals.as<uint32_t>());
+                SER_TRY(hipGetLastError());
+                cvec_status cs = encode_segment(a, a->vals.p, off, total, &a->tail, st);
+                if (cs) return cs;
+            }
+        }
+    }
+    // pointer tables of the segments, then sizes -> offsets
+    std::vector<const uint64_t *> h_off;
+    std::vector<const uint8_t *> h_bytes;
+    for (const Segment &s : a->segs) { h_off.push_back(s.off); h_bytes.push_back(s.bytes); }
+    if (a->tail.bytes) { h_off.push_back(a->tail.off); h_bytes.push_back(a->tail.bytes); }
+    const uint32_t n_seg = (uint32_t)h_off.size();
+    SER_TRY(a->tab_off.need((size_t)n_seg * 8));
+    SER_TRY(a->tab_bytes.need((size_t)n_seg * 8));
+    if (n_seg) {
+        SER_TRY(hipMemcpyAsync(a->tab_off.p, h_off.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
+        SER_TRY(hipMemcpyAsync(a->tab_bytes.p, h_bytes.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
+        SER_TRY(hipStreamSynchronize(st)); // the host vectors go out of scope
+    }
+    uint64_t tot[2] = {0, 0};
+    if (n) {
+        k_ser_sizes<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, reader ? 1 : 0, total_num_rows, a->len.as<uint64_t>(),
+                                                            a->fill.as<uint32_t>(), a->tab_off.as<const uint64_t *>(), n_seg,
+                                                            a->out_size.as<uint64_t>(), a->out_nsec.as<uint64_t>());
+        SER_TRY(launch_exclusive_scan(a->out_size.as<uint64_t>(), n, a->out_off.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
+        SER_TRY(launch_exclusive_scan(a->out_nsec.as<uint64_t>(), n, a->out_sec.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
+        SER_TRY(hipMemcpyAsync(&tot[0], a->out_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        SER_TRY(hipMemcpyAsync(&tot[1], a->out_sec.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        SER_TRY(hipStreamSynchronize(st));
+    } else {
+        SER_TRY(hipMemsetAsync(a->out_off.p, 0, 8, st));
+        SER_TRY(hipMemsetAsync(a->out_sec.p, 0, 8, st));
+        SER_TRY(hipStreamSynchronize(st));
+    }
+    a->sealed = reader ? 2 : 1;
+    a->sealed_rows = total_num_rows;
+    a->sealed_bytes = tot[0];
+    a->sealed_sections = tot[1];
+    if (n_bytes) *n_bytes = tot[0];
+    if (n_sections) *n_sections = tot[1];
+    return CVEC_OK;
+}
+
+cvec_status cvec_series_appender_emit_dev(cvec_series_appender *a, uint8_t *d_bytes, size_t bytes_cap, uint64_t *d_byte_off,
+                                          uint64_t *d_sec_base, void *stream) {
+    if (!a || !a->sealed || !d_byte_off || !d_sec_base) return CVEC_ERR_BAD_ARGUMENT;
+    if (a->sealed_bytes && !d_bytes) return CVEC_ERR_BAD_ARGUMENT;
+    if (bytes_cap < a->sealed_bytes) return CVEC_ERR_CAPACITY;
+    DeviceScope scope(a->device);
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t n = a->n;
+    const int reader = a->sealed == 2;
+    const uint32_t n_seg = (uint32_t)(a->segs.size() + (a->tail.bytes ? 1 : 0));
+    SER_TRY(hipMemcpyAsync(d_byte_off, a->out_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
+    SER_TRY(hipMemcpyAsync(d_sec_base, a->out_sec.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (n) {
+        k_ser_gather<<<wave_blocks(n), SER_THREADS, 0, st>>>(n, a->etype, reader, a->sealed_rows, a->len.as<uint64_t>(),
+                                                             a->fill.as<uint32_t>(), a->nulls.as<uint32_t>(),
+                                                             a->tab_off.as<const uint64_t *>(), a->tab_bytes.as<const uint8_t *>(),
+                                                             n_seg, a->out_off.as<uint64_t>(), d_bytes);
+        SER_TRY(hipGetLastError());
+    }
+    SER_TRY(hipStreamSynchronize(st));
+    if (reader) { // the appender goes on where it was
+        a->sealed = 0;
+        return CVEC_OK;
+    }
+    return clear_state(a, st); // src/vector.rs:368: finish() resets the appender
+}
+
+cvec_status cvec_series_appender_unseal(cvec_series_appender *a) {
+    if (!a) return CVEC_ERR_BAD_ARGUMENT;
+    DeviceScope scope(a->device);
+    if (a->tail.bytes) { (void)hipDeviceSynchronize(); a->drop(a->tail); }
+    a->sealed = 0;
+    return CVEC_OK;
+}
+
+} // extern "C"

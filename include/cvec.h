@@ -414,6 +414,48 @@ cvec_status cvec_appender_finish(cvec_appender *a, uint64_t total_num_rows, uint
  * sections; values in the open section are not visible yet.  Same out / cap / len rules as finish. */
 cvec_status cvec_appender_reader(cvec_appender *a, uint8_t *out, size_t cap, size_t *len);
 
+/* ---- series appender: one VectorAppender<T, W> per series, all of them resident on the device ------- */
+/* What n_series appenders of the crate (src/vector.rs:207-379) do when they are driven side by side, as a
+ * time-series store does on every scrape: each series keeps an open section of up to 255 raw values
+ * (write_buf, :300-307) and the encoded bytes of its complete sections.  The handle holds both in device
+ * memory for all series: an append call that completes sections encodes exactly those sections, for every
+ * series at once, and keeps the result at its encoded size; the raw values of a call are not kept.  The
+ * handle belongs to the device that was current at _new; the calls below are synchronous on `stream`
+ * (they read a few counters back) and, like the reference's &mut self, not thread-safe per handle.
+ * Bytes, element counts and null-section counts equal those of n_series reference appenders that receive
+ * the same calls. */
+typedef struct cvec_series_appender cvec_series_appender;
+cvec_status cvec_series_appender_new(int32_t etype, uint64_t n_series, cvec_series_appender **out);
+void cvec_series_appender_free(cvec_series_appender *a);
+cvec_status cvec_series_appender_reset(cvec_series_appender *a);                    /* :254-262 */
+/* append (src/vector.rs:300-307), many values per call: series v receives d_values[d_elem_off[v] ..
+ * d_elem_off[v+1]); with d_elem_off == NULL every series receives per_series values, d_values being
+ * n_series x per_series row-major.  Element type of the handle, device memory. */
+cvec_status cvec_series_appender_append_dev(cvec_series_appender *a, const void *d_values,
+                                            const uint64_t *d_elem_off /*nullable*/, uint64_t per_series, void *stream);
+/* append_nulls (src/vector.rs:311-335): series v receives d_elem_off[v+1] - d_elem_off[v] nulls, or
+ * per_series with d_elem_off == NULL.  Zeros first fill the open section; whole runs of 256 behind an empty
+ * open section are explicit null sections, counted in the header. */
+cvec_status cvec_series_appender_append_nulls_dev(cvec_series_appender *a, const uint64_t *d_elem_off /*nullable*/,
+                                                  uint64_t per_series, void *stream);
+/* finish (src/vector.rs:344-370, reader == 0) or reader (:372-378, reader != 0) in two steps, because the
+ * caller owns the output.  _seal fixes the contents and reports the size of the resulting batch: for
+ * finish every series is padded with nulls to total_num_rows (CVEC_INVALID_NUM_ROWS with the reference's
+ * two numbers in detail when a series holds more, or total_num_rows exceeds u32; the handle then stays
+ * open); for reader only complete sections are visible.  _emit_dev writes the blob, byte_off[n+1] and
+ * sec_base[n+1] of a batch that the read entry points take as it is; after a finish the handle is empty
+ * again (:368), after a reader it goes on where it was.  No append between the two calls; _unseal gives
+ * up a seal without emitting. */
+cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, uint64_t total_num_rows,
+                                      uint64_t *n_bytes, uint64_t *n_sections, uint64_t detail[2] /*nullable*/,
+                                      void *stream);
+cvec_status cvec_series_appender_emit_dev(cvec_series_appender *a, uint8_t *d_bytes, size_t bytes_cap,
+                                          uint64_t *d_byte_off, uint64_t *d_sec_base, void *stream);
+cvec_status cvec_series_appender_unseal(cvec_series_appender *a);
+/* Device memory held: number of encoded segments, their bytes, and the bytes of open sections and offsets. */
+cvec_status cvec_series_appender_stats(const cvec_series_appender *a, uint64_t *n_segments, uint64_t *encoded_bytes,
+                                       uint64_t *state_bytes);
+
 /* Test hook, no counterpart in the reference: makes the next *_batch call of the calling thread fail
  * with CVEC_ERR_HIP at chunk `chunk` (0-based) after that chunk's copies and kernels have been queued,
  * to exercise the error exit of the pipeline (which must wait for everything in flight before it

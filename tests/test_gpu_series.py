@@ -1,0 +1,143 @@
+"""GPU parity of the series appender (cvec_series_appender_*, through the C ABI): n appenders driven side by side
+on the device against n oracle appenders (the CPU restatement of VectorAppender, src/vector.rs:207-379) that
+receive the same calls.  Bit-exact bytes, element counts and null-section counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NPD = {"u32": np.uint32, "u64": np.uint64, "f32": np.float32}
+
+
+@pytest.fixture(scope="module")
+def cv():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import compressed_vec_amd as cv
+    assert cv.lib().cvec_init(0) == 0
+    return cv
+
+
+def _values(rng, tname, n):
+    mode = int(rng.integers(0, 5))
+    if tname == "f32":
+        if mode == 0:
+            return np.zeros(n, dtype=np.float32)
+        if mode == 1:
+            return np.full(n, 2.5, dtype=np.float32)
+        return (rng.standard_normal(n) * 10.0 ** int(rng.integers(-3, 6))).astype(np.float32)
+    dt = NPD[tname]
+    if mode == 0:
+        return np.zeros(n, dtype=dt)
+    if mode == 1:
+        return np.full(n, 77, dtype=dt)
+    if mode == 2:
+        return (rng.integers(0, 50, size=n) + (1 << 20)).astype(dt)
+    hi = 2 ** (31 if tname == "u32" else 62)
+    return rng.integers(0, hi, size=n).astype(dt)
+
+
+def _same_vectors(host, oracles, total=None, reader=False):
+    for v, o in enumerate(oracles):
+        want = o.reader_bytes() if reader else o.finish(total)
+        assert host.vector(v) == bytes(want), "series %d" % v
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_series_appender_ragged_appends_and_nulls_vs_oracle(cv, oracle, tname):
+    """Ragged appends, ragged and uniform nulls, readers in between, finish with padding; then the handle again."""
+    rng = np.random.default_rng({"u32": 5, "u64": 6, "f32": 7}[tname])
+    n = 37
+    et = {"u32": oracle.U32, "u64": oracle.U64, "f32": oracle.F32}[tname]
+    app = cv.SeriesAppender(tname, n)
+    for round_ in range(2):
+        oracles = [oracle.Appender(et, 64) for _ in range(n)]
+        seen = [[] for _ in range(n)]
+        for step in range(9):
+            kind = step % 4
+            if kind in (0, 1, 3):
+                counts = rng.integers(0, 400 if kind != 3 else 3, size=n)
+                counts[rng.integers(0, n)] = 0
+                off = np.zeros(n + 1, dtype=np.int64)
+                off[1:] = np.cumsum(counts)
+                vals = np.concatenate([_values(rng, tname, int(c)) for c in counts]) if off[-1] else np.zeros(0, NPD[tname])
+                app.append(vals, off)
+                for v, o in enumerate(oracles):
+                    o.append_many(vals[off[v]:off[v + 1]])
+                    seen[v].append(vals[off[v]:off[v + 1]])
+            else:
+                counts = rng.integers(0, 900, size=n)
+                counts[::5] = 0
+                app.append_nulls(counts)
+                for v, o in enumerate(oracles):
+                    if counts[v]:
+                        o.append_nulls(int(counts[v]))
+                    seen[v].append(np.zeros(int(counts[v]), NPD[tname]))
+            if step in (3, 7):
+                _same_vectors(app.reader().download(), oracles, reader=True)
+        app.append_nulls(300)
+        for o in oracles:
+            o.append_nulls(300)
+        longest = max(o.num_elements() for o in oracles)
+        with pytest.raises(cv.CodingError) as e:
+            app.finish(longest - 1)
+        assert e.value.name == "InvalidNumRows" and e.value.detail == (longest - 1, longest)
+        total = longest + (0 if round_ else 700)
+        batch = app.finish(total)
+        _same_vectors(batch.download(), oracles, total=total)
+        assert app.stats()["segments"] == 0            # finish() leaves the appender empty
+        # what came out is a batch like any other: decode it and compare with the values that went in
+        per = (total + 255) // 256
+        assert batch.n_sections == n * per
+        dec = batch.decode()[0].reshape(n, per * 256)
+        bits = np.uint32 if tname != "u64" else np.uint64
+        for v in range(n):
+            went_in = np.concatenate(seen[v] + [np.zeros(0, NPD[tname])])
+            assert np.array_equal(dec[v, :went_in.size].view(bits), went_in.view(bits)) and not dec[v, went_in.size:].any()
+
+
+def test_series_appender_uniform_scrapes_vs_oracle(cv, oracle):
+    """The scrape pattern: every series receives k values per call; sections complete for all series at once."""
+    import torch
+    rng = np.random.default_rng(11)
+    n, k, calls = 300, 48, 13                          # 624 values per series: two complete sections + 112 open
+    app = cv.SeriesAppender("f32", n)
+    oracles = [oracle.Appender(oracle.F32, 64) for _ in range(n)]
+    base = rng.standard_normal(n).astype(np.float32) * 100
+    blocks = []
+    for c in range(calls):
+        block = (base[:, None] + np.sin(np.arange(c * k, (c + 1) * k, dtype=np.float32) / 9.0)[None, :]).astype(np.float32)
+        blocks.append(block)
+        app.append(torch.from_numpy(block).cuda())
+        for v, o in enumerate(oracles):
+            o.append_many(block[v])
+    st = app.stats()
+    assert st["segments"] == 2                          # calls 6 and 11 complete a section of every series
+    _same_vectors(app.reader().download(), oracles, reader=True)
+    batch = app.finish(calls * k)
+    _same_vectors(batch.download(), oracles, total=calls * k)
+    # the batch is usable as it is
+    got = batch.decode()[0].reshape(n, -1)[:, :calls * k]
+    assert got.shape == (n, calls * k)
+    assert np.array_equal(np.ascontiguousarray(got).view(np.uint32), np.concatenate(blocks, 1).view(np.uint32))
+    assert int(batch.filter_count(float(got[3, 5]))) == int((got == got[3, 5]).sum())
+
+
+def test_series_appender_empty_and_argument_errors(cv, oracle):
+    app = cv.SeriesAppender("u32", 5)
+    empty = app.finish(0).download()
+    o = oracle.Appender(oracle.U32, 64)
+    want = bytes(o.finish(0))
+    assert all(empty.vector(v) == want for v in range(5))
+    assert app.reader().n_sections == 0
+    with pytest.raises(cv.CodingError):
+        app.append(np.zeros((4, 3), dtype=np.uint32))                     # wrong number of series
+    with pytest.raises(cv.CodingError):
+        app.append(np.zeros(3, dtype=np.uint32), [0, 1, 2, 3, 4, 5])      # offsets reach past the values
+    with pytest.raises(cv.CodingError):
+        app.append(np.zeros((5, 3), dtype=np.float32))                    # element type
+    with pytest.raises(cv.CodingError) as e:
+        app.finish(2 ** 32)
+    assert e.value.detail == (2 ** 32, 2 ** 32 - 1)
+    zero = cv.SeriesAppender("u64", 0)
+    assert zero.finish(10).n_vectors == 0
