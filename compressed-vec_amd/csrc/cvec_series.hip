@@ -52,10 +52,40 @@ struct Buf { // grow-only device buffer
     template <class T> T *as() const { return (T *)p; }
 };
 
-struct Segment {
+struct Segment { // both arrays live in the handle's arena
     uint8_t *bytes = nullptr;
     uint64_t *off = nullptr; // n + 1
     uint64_t n_bytes = 0;
+};
+
+// Segment storage: slabs of device memory handed out front to back.  A finish() or reset() rewinds the slabs
+// and keeps them, so a handle that is filled again and again allocates only while it grows.
+struct Arena {
+    struct Slab { uint8_t *p; size_t cap, used; };
+    std::vector<Slab> slabs;
+    static constexpr size_t SLAB_MIN = (size_t)4 << 20, SLAB_MAX = (size_t)256 << 20;
+    ~Arena() { release(); }
+    void release() {
+        for (Slab &s : slabs) (void)hipFree(s.p);
+        slabs.clear();
+    }
+    void rewind() { for (Slab &s : slabs) s.used = 0; }
+    hipError_t take(size_t bytes, void **out) {
+        bytes = (bytes + 255) / 256 * 256;
+        for (Slab &s : slabs)
+            if (s.cap - s.used >= bytes) { *out = s.p + s.used; s.used += bytes; return hipSuccess; }
+        size_t cap = 8 * bytes;
+        cap = cap < SLAB_MIN ? SLAB_MIN : cap > SLAB_MAX ? SLAB_MAX : cap;
+        cap = cap < bytes ? bytes : cap;
+        Slab s{nullptr, cap, bytes};
+        hipError_t e = hipMalloc((void **)&s.p, cap);
+        if (e != hipSuccess && cap > bytes) { s.cap = bytes; e = hipMalloc((void **)&s.p, bytes); } // a tight fit as the last resort
+        if (e != hipSuccess) return e;
+        slabs.push_back(s);
+        *out = s.p;
+        return hipSuccess;
+    }
+    size_t reserved() const { size_t t = 0; for (const Slab &s : slabs) t += s.cap; return t; }
 };
 
 // ---- kernels ---------------------------------------------------------------------------------------------
@@ -205,7 +235,23 @@ __global__ __launch_bounds__(SER_THREADS) void k_ser_gather(uint64_t n, int etyp
         const uint64_t s0 = o[v] + HEADER_BYTES, s1 = o[v + 1];
         const uint8_t *src = seg_bytes[s] + s0;
         const uint64_t m = s1 - s0;
-        for (uint64_t i = lane; i < m; i += 64) dst[i] = src[i];
+        // sections start at any byte: bytes up to the destination's next 16-byte boundary, whole 16-byte
+        // pieces (aligned stores, loads at whatever phase the source has), bytes after the last piece
+        uint64_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+        head = head < m ? head : m;
+        if (lane < head) dst[lane] = src[lane];
+        const uint64_t pieces = (m - head) / 16;
+        for (uint64_t j = lane; j < pieces; j += 64) {
+            const uint8_t *sp = src + head + 16 * j;
+            uint4 x;
+            x.x = *(const u32u *)(sp + 0);
+            x.y = *(const u32u *)(sp + 4);
+            x.z = *(const u32u *)(sp + 8);
+            x.w = *(const u32u *)(sp + 12);
+            *(uint4 *)(dst + head + 16 * j) = x;
+        }
+        const uint64_t done = head + 16 * pieces;
+        if (lane < m - done) dst[done + lane] = src[done + lane];
         dst += m;
     }
 }
@@ -224,21 +270,13 @@ struct cvec_series_appender {
     Buf cnt, off, scan_tmp, vals;        // per call: elements leaving per series, their scan, the values
     Buf enc_bytes, enc_off, enc_sec, enc_res, enc_ws;
     Buf out_size, out_off, out_nsec, out_sec, tab_off, tab_bytes, maxlen;
+    Arena arena;
     std::vector<Segment> segs;
-    Segment tail;
+    Segment tail;                        // finish()'s closing segment, between seal and emit
     int sealed = 0;                      // 0 open, 1 sealed for finish, 2 sealed for reader
     uint64_t sealed_rows = 0, sealed_bytes = 0, sealed_sections = 0;
     uint64_t resident_bytes = 0;
 
-    void drop(Segment &s) {
-        if (s.bytes) (void)hipFree(s.bytes);
-        if (s.off) (void)hipFree(s.off);
-        s = Segment();
-    }
-    ~cvec_series_appender() {
-        for (Segment &s : segs) drop(s);
-        drop(tail);
-    }
 };
 
 #define SER_TRY(expr)                                                        \
@@ -263,9 +301,9 @@ cvec_status clear_state(cvec_series_appender *a, hipStream_t st) {
     SER_TRY(hipMemsetAsync(a->len.p, 0, a->n * 8 + 16, st));
     SER_TRY(hipMemsetAsync(a->nulls.p, 0, a->n * 4 + 16, st));
     SER_TRY(hipStreamSynchronize(st));
-    for (Segment &s : a->segs) a->drop(s);
     a->segs.clear();
-    a->drop(a->tail);
+    a->tail = Segment();
+    a->arena.rewind();
     a->sealed = 0;
     a->resident_bytes = 0;
     return CVEC_OK;
@@ -289,14 +327,12 @@ cvec_status encode_segment(cvec_series_appender *a, const void *vals, const uint
     SER_TRY(hipStreamSynchronize(st));
     if (n_bytes < n * HEADER_BYTES || n_bytes > cap) return CVEC_ERR_HIP;
     Segment s;
-    SER_TRY(hipMalloc((void **)&s.bytes, n_bytes + 16));
-    hipError_t e = hipMalloc((void **)&s.off, (n + 1) * 8);
-    if (e != hipSuccess) { (void)hipFree(s.bytes); return record_hip_error(e, "hipMalloc(segment offsets)"); }
+    SER_TRY(a->arena.take(n_bytes + 16, (void **)&s.bytes));
+    SER_TRY(a->arena.take((n + 1) * 8, (void **)&s.off));
     s.n_bytes = n_bytes;
-    e = hipMemcpyAsync(s.bytes, a->enc_bytes.p, n_bytes, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(s.off, a->enc_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(s.bytes); (void)hipFree(s.off); return record_hip_error(e, "segment copy"); }
+    SER_TRY(hipMemcpyAsync(s.bytes, a->enc_bytes.p, n_bytes, hipMemcpyDeviceToDevice, st));
+    SER_TRY(hipMemcpyAsync(s.off, a->enc_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
+    SER_TRY(hipStreamSynchronize(st)); // the encode buffers are reused by the next call, whatever its stream
     *seg = s;
     return CVEC_OK;
 }
@@ -407,6 +443,7 @@ cvec_status cvec_series_appender_stats(const cvec_series_appender *a, uint64_t *
     if (n_segments) *n_segments = a->segs.size();
     if (encoded_bytes) *encoded_bytes = a->resident_bytes;
     if (state_bytes) *state_bytes = a->n * ((uint64_t)FIXED_LEN * a->width + 16) + a->segs.size() * (a->n + 1) * 8;
+    // (the slabs behind the segments may hold more than encoded_bytes: they are kept across finish() and reset())
     return CVEC_OK;
 }
 
@@ -523,7 +560,7 @@ cvec_status cvec_series_appender_emit_dev(cvec_series_appender *a, uint8_t *d_by
 cvec_status cvec_series_appender_unseal(cvec_series_appender *a) {
     if (!a) return CVEC_ERR_BAD_ARGUMENT;
     DeviceScope scope(a->device);
-    if (a->tail.bytes) { (void)hipDeviceSynchronize(); a->drop(a->tail); }
+    a->tail = Segment(); // its arena space comes back with the next finish() or reset()
     a->sealed = 0;
     return CVEC_OK;
 }

@@ -78,6 +78,23 @@ def test_appender_argument_errors():
         cv.make_pred(cv.U32, list(range(17)))
 
 
+def test_series_appender_rejects_bad_arguments_without_a_gpu():
+    import ctypes as C
+    import compressed_vec_amd as cv
+    lib = cv.lib()
+    bad = 101                                                   # CVEC_ERR_BAD_ARGUMENT
+    h = C.c_void_p()
+    assert lib.cvec_series_appender_new(0x55, 4, C.byref(h)) == bad and not h.value      # no such element type
+    assert lib.cvec_series_appender_new(cv.U32, 2 ** 32, C.byref(h)) == bad
+    assert lib.cvec_series_appender_new(cv.U32, 4, None) == bad
+    assert lib.cvec_series_appender_append_dev(None, None, None, 3, None) == bad
+    assert lib.cvec_series_appender_append_nulls_dev(None, None, 3, None) == bad
+    assert lib.cvec_series_appender_seal(None, 0, 0, None, None, None, None) == bad
+    assert lib.cvec_series_appender_emit_dev(None, None, 0, None, None, None) == bad
+    assert lib.cvec_series_appender_reset(None) == bad and lib.cvec_series_appender_unseal(None) == bad
+    lib.cvec_series_appender_free(None)
+
+
 def test_synth_generator_matches_bench_shape():
     from compressed_vec_amd import synth
     v = synth.sinewave_varnonzeros_u32(1.0, 10000)

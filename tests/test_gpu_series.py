@@ -141,3 +141,23 @@ def test_series_appender_empty_and_argument_errors(cv, oracle):
     assert e.value.detail == (2 ** 32, 2 ** 32 - 1)
     zero = cv.SeriesAppender("u64", 0)
     assert zero.finish(10).n_vectors == 0
+
+
+def test_series_appender_at_shard_width_equals_one_shot_encode(cv):
+    """Size-independent property at the headline vector length: 16384 series x 2048 f32 values, appended 96 per call
+    (sections complete in the middle of calls), finish() == encode of the whole matrix at once, byte for byte,
+    offsets and section bases included; the handle, used again, gives the same batch."""
+    import torch
+    from compressed_vec_amd import synth
+    n, length, k = 16384, 2048, 96
+    mat = torch.cat([synth.batch_values_torch("f32_xor", 4096, length, v_first=c0)[0] for c0 in range(0, n, 4096)]).reshape(n, length)
+    eo = torch.arange(n + 1, device="cuda", dtype=torch.int64) * length
+    want = cv.encode_device("f32", mat.reshape(-1), eo)
+    app = cv.SeriesAppender("f32", n)
+    for _ in range(2):
+        for c0 in range(0, length, k):
+            app.append(mat[:, c0:c0 + k].contiguous())
+        got = app.finish(length)
+        assert got.n_bytes == want.n_bytes and got.n_sections == want.n_sections
+        assert torch.equal(got.d_bytes[:got.n_bytes], want.d_bytes[:want.n_bytes])
+        assert torch.equal(got.d_byte_off, want.d_byte_off) and torch.equal(got.d_sec_base, want.d_sec_base)
