@@ -423,7 +423,7 @@ cvec_status cvec_appender_reader(cvec_appender *a, uint8_t *out, size_t cap, siz
  * handle belongs to the device that was current at _new; the calls below are synchronous on `stream`
  * (they read a few counters back) and, like the reference's &mut self, not thread-safe per handle.
  * Bytes, element counts and null-section counts equal those of n_series reference appenders that receive
- * the same calls. */
+ * the same calls.  A call that fails with CVEC_ERR_HIP may have applied part of its effect: reset the handle. */
 typedef struct cvec_series_appender cvec_series_appender;
 cvec_status cvec_series_appender_new(int32_t etype, uint64_t n_series, cvec_series_appender **out);
 void cvec_series_appender_free(cvec_series_appender *a);
