@@ -9,8 +9,11 @@
 //   segments                 every append call that completes sections encodes exactly those sections, for all
 //                            series at once, with the batch encoder; the result (one short vector per series, header
 //                            included, empty where nothing completed) is kept as a segment at its exact size
-// seal() encodes what finish() adds (the open section padded with zeros and the null sections up to
-// total_num_rows, src/vector.rs:344-359) as a last segment and computes the byte offsets of the final vectors;
+//                            A run of whole null sections (append_nulls behind an empty open section, finish's
+//                            padding) is one 0x00 byte per section in the vector: such a segment is only a count per
+//                            series, whatever the length of the run
+// seal() adds what finish() adds (the open section padded with zeros as an encoded segment, the null sections up
+// to total_num_rows as a count, src/vector.rs:344-359) and computes the byte offsets of the final vectors;
 // emit() writes, per series, one header (element and null-section counts, src/vector.rs:160-169) followed by the
 // section bytes of all segments in order.  Sections are independent of their neighbours, so the bytes equal the
 // reference appender's for the same sequence of calls.
@@ -52,9 +55,10 @@ struct Buf { // grow-only device buffer
     template <class T> T *as() const { return (T *)p; }
 };
 
-struct Segment { // both arrays live in the handle's arena
+struct Segment { // the arrays live in the handle's arena
     uint8_t *bytes = nullptr;
-    uint64_t *off = nullptr; // n + 1
+    uint64_t *off = nullptr;     // n + 1
+    uint64_t *null_run = nullptr; // instead of bytes / off: series v continues with null_run[v] null sections (one 0x00 byte each)
     uint64_t n_bytes = 0;
 };
 
@@ -93,11 +97,12 @@ struct Arena {
 // One lane per series: how many values arrive and how many of open + new leave as complete sections.
 __global__ void k_ser_plan(uint64_t n, const uint64_t *__restrict__ elem_off, uint64_t per_vector, int nulls_mode,
                            const uint32_t *__restrict__ fill, uint64_t *__restrict__ len, uint32_t *__restrict__ nulls,
-                           uint64_t *__restrict__ flush_cnt) {
+                           uint64_t *__restrict__ flush_cnt, uint64_t *__restrict__ null_run) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const uint64_t c = elem_off ? elem_off[v + 1] - elem_off[v] : per_vector;
     const uint32_t f = fill[v];
+    uint64_t flush = ((uint64_t)f + c) / FIXED_LEN * FIXED_LEN, run = 0;
     if (nulls_mode) {
         // src/vector.rs:311-335: zeros fill the open section first; whole runs of 256 behind an empty open
         // section are explicit null sections
@@ -110,9 +115,15 @@ __global__ void k_ser_plan(uint64_t n, const uint64_t *__restrict__ elem_off, ui
             left -= fillup;
         }
         if (open == 0) nulls[v] += (uint32_t)(left / FIXED_LEN);
+        // only the section that the zeros complete goes through the encoder; the whole sections of zeros behind it
+        // are one byte each, whatever their number, and are kept as a count
+        const uint64_t sections = flush / FIXED_LEN;
+        flush = (f != 0 && sections != 0) ? FIXED_LEN : 0;
+        run = sections - flush / FIXED_LEN;
     }
     len[v] += c;
-    flush_cnt[v] = ((uint64_t)f + c) / FIXED_LEN * FIXED_LEN;
+    flush_cnt[v] = flush;
+    null_run[v] = run;
 }
 
 // One wave per series: the first out_off[v+1] - out_off[v] elements of (open section ++ new values ++ zeros).
@@ -175,23 +186,29 @@ __global__ void k_ser_max_len(uint64_t n, const uint64_t *__restrict__ len, unsi
 
 // One lane per series: elements of the closing segment (open section + zeros up to total_rows).
 __global__ void k_ser_tail_plan(uint64_t n, uint64_t total_rows, const uint64_t *__restrict__ len,
-                                const uint32_t *__restrict__ fill, uint64_t *__restrict__ tail_cnt) {
+                                const uint32_t *__restrict__ fill, uint64_t *__restrict__ tail_cnt,
+                                uint64_t *__restrict__ null_run) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    const uint64_t flushed = len[v] - fill[v];
-    tail_cnt[v] = total_rows >= flushed ? total_rows - flushed : 0;
+    // src/vector.rs:352-359: the open section is rounded out with zeros (the encoder pads a short last section),
+    // then null sections follow until total_rows is covered
+    const uint32_t f = fill[v];
+    const uint64_t padded = len[v] - f + (f ? FIXED_LEN : 0);
+    tail_cnt[v] = f;
+    null_run[v] = total_rows > padded ? (total_rows - padded + FIXED_LEN - 1) / FIXED_LEN : 0;
 }
 
 // One lane per series: size of the final vector and its number of sections.
 __global__ void k_ser_sizes(uint64_t n, int reader, uint64_t total_rows, const uint64_t *__restrict__ len,
-                            const uint32_t *__restrict__ fill, const uint64_t *const *__restrict__ seg_off, uint32_t n_seg,
+                            const uint32_t *__restrict__ fill, const uint64_t *const *__restrict__ seg_off,
+                            const uint64_t *const *__restrict__ seg_null, uint32_t n_seg,
                             uint64_t *__restrict__ out_size, uint64_t *__restrict__ out_nsec) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
     uint64_t size = HEADER_BYTES;
     for (uint32_t s = 0; s < n_seg; s++) {
         const uint64_t *o = seg_off[s];
-        size += o[v + 1] - o[v] - HEADER_BYTES;
+        size += o ? o[v + 1] - o[v] - HEADER_BYTES : seg_null[s][v];
     }
     const uint64_t elems = reader ? len[v] - fill[v] : total_rows;
     out_size[v] = size;
@@ -203,7 +220,8 @@ __global__ __launch_bounds__(SER_THREADS) void k_ser_gather(uint64_t n, int etyp
                                                             const uint64_t *__restrict__ len, const uint32_t *__restrict__ fill,
                                                             const uint32_t *__restrict__ nulls,
                                                             const uint64_t *const *__restrict__ seg_off,
-                                                            const uint8_t *const *__restrict__ seg_bytes, uint32_t n_seg,
+                                                            const uint8_t *const *__restrict__ seg_bytes,
+                                                            const uint64_t *const *__restrict__ seg_null, uint32_t n_seg,
                                                             const uint64_t *__restrict__ byte_off, uint8_t *__restrict__ bytes) {
     const uint64_t v = (uint64_t)blockIdx.x * SER_WAVES + threadIdx.x / 64;
     const uint32_t lane = threadIdx.x & 63;
@@ -232,6 +250,12 @@ __global__ __launch_bounds__(SER_THREADS) void k_ser_gather(uint64_t n, int etyp
     dst += HEADER_BYTES;
     for (uint32_t s = 0; s < n_seg; s++) {
         const uint64_t *o = seg_off[s];
+        if (o == nullptr) { // a run of null sections: NullFixedSect is the one byte 0x00 (src/section.rs:440-443)
+            const uint64_t m = seg_null[s][v];
+            for (uint64_t i = lane; i < m; i += 64) dst[i] = 0;
+            dst += m;
+            continue;
+        }
         const uint64_t s0 = o[v] + HEADER_BYTES, s1 = o[v + 1];
         const uint8_t *src = seg_bytes[s] + s0;
         const uint64_t m = s1 - s0;
@@ -268,11 +292,12 @@ struct cvec_series_appender {
     uint32_t width = 4;
     Buf stage, fill, len, nulls;         // per series state
     Buf cnt, off, scan_tmp, vals;        // per call: elements leaving per series, their scan, the values
+    Buf run, run_scan;                   // per call: null sections per series that are kept as a count, their scan
     Buf enc_bytes, enc_off, enc_sec, enc_res, enc_ws;
-    Buf out_size, out_off, out_nsec, out_sec, tab_off, tab_bytes, maxlen;
+    Buf out_size, out_off, out_nsec, out_sec, tab_off, tab_bytes, tab_null, maxlen;
     Arena arena;
     std::vector<Segment> segs;
-    Segment tail;                        // finish()'s closing segment, between seal and emit
+    std::vector<Segment> tail;           // finish()'s closing segments (open section, null run), between seal and emit
     int sealed = 0;                      // 0 open, 1 sealed for finish, 2 sealed for reader
     uint64_t sealed_rows = 0, sealed_bytes = 0, sealed_sections = 0;
     uint64_t resident_bytes = 0;
@@ -302,7 +327,7 @@ cvec_status clear_state(cvec_series_appender *a, hipStream_t st) {
     SER_TRY(hipMemsetAsync(a->nulls.p, 0, a->n * 4 + 16, st));
     SER_TRY(hipStreamSynchronize(st));
     a->segs.clear();
-    a->tail = Segment();
+    a->tail.clear();
     a->arena.rewind();
     a->sealed = 0;
     a->resident_bytes = 0;
@@ -337,13 +362,31 @@ cvec_status encode_segment(cvec_series_appender *a, const void *vals, const uint
     return CVEC_OK;
 }
 
+// Keeps the counts in a->run as a segment of null sections if any series has one.
+cvec_status null_run_segment(cvec_series_appender *a, std::vector<Segment> *to, hipStream_t st) {
+    const uint64_t n = a->n;
+    SER_TRY(launch_exclusive_scan(a->run.as<uint64_t>(), n, a->run_scan.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
+    uint64_t total = 0;
+    SER_TRY(hipMemcpyAsync(&total, a->run_scan.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    SER_TRY(hipStreamSynchronize(st));
+    if (total == 0) return CVEC_OK;
+    Segment s;
+    SER_TRY(a->arena.take(n * 8, (void **)&s.null_run));
+    SER_TRY(hipMemcpyAsync(s.null_run, a->run.p, n * 8, hipMemcpyDeviceToDevice, st));
+    SER_TRY(hipStreamSynchronize(st));
+    s.n_bytes = total;
+    to->push_back(s);
+    a->resident_bytes += n * 8;
+    return CVEC_OK;
+}
+
 template <class U>
 cvec_status append_t(cvec_series_appender *a, const void *d_values, const uint64_t *d_elem_off, uint64_t per_vector,
                      int nulls_mode, hipStream_t st) {
     const uint64_t n = a->n;
     uint64_t *cnt = a->cnt.as<uint64_t>(), *off = a->off.as<uint64_t>();
     k_ser_plan<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, d_elem_off, per_vector, nulls_mode, a->fill.as<uint32_t>(),
-                                                       a->len.as<uint64_t>(), a->nulls.as<uint32_t>(), cnt);
+                                                       a->len.as<uint64_t>(), a->nulls.as<uint32_t>(), cnt, a->run.as<uint64_t>());
     SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
     uint64_t total = 0;
     SER_TRY(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
@@ -365,6 +408,7 @@ cvec_status append_t(cvec_series_appender *a, const void *d_values, const uint64
     } else {
         SER_TRY(hipStreamSynchronize(st)); // the caller's values may be reused when the call returns
     }
+    if (nulls_mode) return null_run_segment(a, &a->segs, st); // behind the section that the zeros completed
     return CVEC_OK;
 }
 
@@ -402,6 +446,8 @@ cvec_status cvec_series_appender_new(int32_t etype, uint64_t n_series, cvec_seri
     if (e == hipSuccess) e = a->cnt.need((n + 1) * 8);
     if (e == hipSuccess) e = a->off.need((n + 1) * 8);
     if (e == hipSuccess) e = a->scan_tmp.need(scan_scratch_words(n) * 8);
+    if (e == hipSuccess) e = a->run.need((n + 1) * 8);
+    if (e == hipSuccess) e = a->run_scan.need((n + 1) * 8);
     if (e == hipSuccess) e = a->out_size.need((n + 1) * 8);
     if (e == hipSuccess) e = a->out_off.need((n + 1) * 8);
     if (e == hipSuccess) e = a->out_nsec.need((n + 1) * 8);
@@ -442,7 +488,7 @@ cvec_status cvec_series_appender_stats(const cvec_series_appender *a, uint64_t *
     if (!a) return CVEC_ERR_BAD_ARGUMENT;
     if (n_segments) *n_segments = a->segs.size();
     if (encoded_bytes) *encoded_bytes = a->resident_bytes;
-    if (state_bytes) *state_bytes = a->n * ((uint64_t)FIXED_LEN * a->width + 16) + a->segs.size() * (a->n + 1) * 8;
+    if (state_bytes) *state_bytes = a->n * ((uint64_t)FIXED_LEN * a->width + 16) + a->segs.size() * (a->n + 1) * 8; // (a null run's counts are in encoded_bytes)
     // (the slabs behind the segments may hold more than encoded_bytes: they are kept across finish() and reset())
     return CVEC_OK;
 }
@@ -474,7 +520,7 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
         if (n) {
             uint64_t *cnt = a->cnt.as<uint64_t>(), *off = a->off.as<uint64_t>();
             k_ser_tail_plan<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, total_num_rows, a->len.as<uint64_t>(),
-                                                                    a->fill.as<uint32_t>(), cnt);
+                                                                    a->fill.as<uint32_t>(), cnt, a->run.as<uint64_t>());
             SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
             uint64_t total = 0;
             SER_TRY(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
@@ -488,28 +534,35 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
                     k_ser_flush<uint32_t><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, nullptr, nullptr, 0, a->stage.as<uint32_t>(),
                                                                                   a->fill.as<uint32_t>(), off, a->vals.as<uint32_t>());
                 SER_TRY(hipGetLastError());
-                cvec_status cs = encode_segment(a, a->vals.p, off, total, &a->tail, st);
+                Segment t;
+                cvec_status cs = encode_segment(a, a->vals.p, off, total, &t, st);
                 if (cs) return cs;
+                a->tail.push_back(t);
             }
+            cvec_status cs = null_run_segment(a, &a->tail, st);
+            if (cs) { a->tail.clear(); return cs; }
         }
     }
     // pointer tables of the segments, then sizes -> offsets
-    std::vector<const uint64_t *> h_off;
+    std::vector<const uint64_t *> h_off, h_null;
     std::vector<const uint8_t *> h_bytes;
-    for (const Segment &s : a->segs) { h_off.push_back(s.off); h_bytes.push_back(s.bytes); }
-    if (a->tail.bytes) { h_off.push_back(a->tail.off); h_bytes.push_back(a->tail.bytes); }
+    for (const std::vector<Segment> *list : {&a->segs, &a->tail})
+        for (const Segment &s : *list) { h_off.push_back(s.off); h_bytes.push_back(s.bytes); h_null.push_back(s.null_run); }
     const uint32_t n_seg = (uint32_t)h_off.size();
     SER_TRY(a->tab_off.need((size_t)n_seg * 8));
     SER_TRY(a->tab_bytes.need((size_t)n_seg * 8));
+    SER_TRY(a->tab_null.need((size_t)n_seg * 8));
     if (n_seg) {
         SER_TRY(hipMemcpyAsync(a->tab_off.p, h_off.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
         SER_TRY(hipMemcpyAsync(a->tab_bytes.p, h_bytes.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
+        SER_TRY(hipMemcpyAsync(a->tab_null.p, h_null.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
         SER_TRY(hipStreamSynchronize(st)); // the host vectors go out of scope
     }
     uint64_t tot[2] = {0, 0};
     if (n) {
         k_ser_sizes<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, reader ? 1 : 0, total_num_rows, a->len.as<uint64_t>(),
-                                                            a->fill.as<uint32_t>(), a->tab_off.as<const uint64_t *>(), n_seg,
+                                                            a->fill.as<uint32_t>(), a->tab_off.as<const uint64_t *>(),
+                                                            a->tab_null.as<const uint64_t *>(), n_seg,
                                                             a->out_size.as<uint64_t>(), a->out_nsec.as<uint64_t>());
         SER_TRY(launch_exclusive_scan(a->out_size.as<uint64_t>(), n, a->out_off.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
         SER_TRY(launch_exclusive_scan(a->out_nsec.as<uint64_t>(), n, a->out_sec.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
@@ -539,14 +592,14 @@ cvec_status cvec_series_appender_emit_dev(cvec_series_appender *a, uint8_t *d_by
     hipStream_t st = (hipStream_t)stream;
     const uint64_t n = a->n;
     const int reader = a->sealed == 2;
-    const uint32_t n_seg = (uint32_t)(a->segs.size() + (a->tail.bytes ? 1 : 0));
+    const uint32_t n_seg = (uint32_t)(a->segs.size() + a->tail.size());
     SER_TRY(hipMemcpyAsync(d_byte_off, a->out_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
     SER_TRY(hipMemcpyAsync(d_sec_base, a->out_sec.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
     if (n) {
         k_ser_gather<<<wave_blocks(n), SER_THREADS, 0, st>>>(n, a->etype, reader, a->sealed_rows, a->len.as<uint64_t>(),
                                                              a->fill.as<uint32_t>(), a->nulls.as<uint32_t>(),
                                                              a->tab_off.as<const uint64_t *>(), a->tab_bytes.as<const uint8_t *>(),
-                                                             n_seg, a->out_off.as<uint64_t>(), d_bytes);
+                                                             a->tab_null.as<const uint64_t *>(), n_seg, a->out_off.as<uint64_t>(), d_bytes);
         SER_TRY(hipGetLastError());
     }
     SER_TRY(hipStreamSynchronize(st));
@@ -560,7 +613,7 @@ cvec_status cvec_series_appender_emit_dev(cvec_series_appender *a, uint8_t *d_by
 cvec_status cvec_series_appender_unseal(cvec_series_appender *a) {
     if (!a) return CVEC_ERR_BAD_ARGUMENT;
     DeviceScope scope(a->device);
-    a->tail = Segment(); // its arena space comes back with the next finish() or reset()
+    a->tail.clear(); // their arena space comes back with the next finish() or reset()
     a->sealed = 0;
     return CVEC_OK;
 }

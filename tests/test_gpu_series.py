@@ -161,3 +161,36 @@ def test_series_appender_at_shard_width_equals_one_shot_encode(cv):
         assert got.n_bytes == want.n_bytes and got.n_sections == want.n_sections
         assert torch.equal(got.d_bytes[:got.n_bytes], want.d_bytes[:want.n_bytes])
         assert torch.equal(got.d_byte_off, want.d_byte_off) and torch.equal(got.d_sec_base, want.d_sec_base)
+
+
+def test_series_appender_long_null_runs_cost_a_count_not_their_length(cv, oracle):
+    """append_nulls and finish padding far beyond what the values take: whole null sections are one byte each in the
+    vector (src/vector.rs:320-327) and a count per series in the handle."""
+    rng = np.random.default_rng(23)
+    n = 19
+    app = cv.SeriesAppender("u64", n)
+    oracles = [oracle.Appender(oracle.U64, 64) for _ in range(n)]
+    first = rng.integers(0, 300, size=n)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum(first)
+    vals = rng.integers(1, 1 << 40, size=int(off[-1])).astype(np.uint64)
+    app.append(vals, off)
+    for v, o in enumerate(oracles):
+        o.append_many(vals[off[v]:off[v + 1]])
+    runs = rng.integers(0, 40_000_000, size=n)
+    runs[3], runs[4] = 0, 255
+    app.append_nulls(runs)
+    for v, o in enumerate(oracles):
+        if runs[v]:
+            o.append_nulls(int(runs[v]))
+    held = app.stats()
+    assert held["encoded_bytes"] < 1 << 20                  # not the gigabytes the zeros would take
+    tail = rng.integers(1, 1 << 20, size=(n, 70)).astype(np.uint64)
+    app.append(tail)
+    for v, o in enumerate(oracles):
+        o.append_many(tail[v])
+    _same_vectors(app.reader().download(), oracles, reader=True)
+    total = 3_000_000_000                                    # finish pads every series to three billion rows
+    batch = app.finish(total)
+    assert batch.n_sections == n * ((total + 255) // 256)
+    _same_vectors(batch.download(), oracles, total=total)
