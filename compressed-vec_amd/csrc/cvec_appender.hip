@@ -1,10 +1,11 @@
 // cvec_appender.hip — VectorAppender<T, W> (reference src/vector.rs:207-379) behind the C ABI.
 //
 // One vector is far below the granularity of a GPU launch, so the handle keeps what the reference keeps in
-// `write_buf` / `stats` on the host: the values appended so far, how many of them sit in the open (not yet
-// complete) section, and the number of explicit null sections (src/vector.rs:321-327).  finish() and reader()
-// encode on the GPU through cvec_encode_batch and write the null-section count into the vector header
-// (offset 12, FixedSectStats, src/vector.rs:160-169), so the bytes equal the reference appender's.
+// `write_buf` / `stats` on the host: the open (not yet complete) section, the values of the complete sections,
+// and the runs and number of explicit null sections (src/vector.rs:321-327), which are kept as counts.
+// finish() and reader() encode the value sections on the GPU through cvec_encode_batch, put the null sections'
+// bytes between them and write the header (FixedSectStats, src/vector.rs:160-169), so the bytes equal the
+// reference appender's.
 #include <cstring>
 #include <new>
 #include <vector>
@@ -20,45 +21,103 @@ inline size_t width(int32_t etype) { return etype == CVEC_U64 ? 8 : 4; }
 struct cvec_appender {
     int32_t etype;
     size_t initial_capacity;
-    std::vector<uint8_t> values; // element bytes, nulls as zeros
+    // Sections are independent of their neighbours, so the handle keeps a vector as a list of runs: runs of
+    // sections that hold appended values (their 256 elements each in `values`, nulls among them as zeros) and
+    // runs of explicit null sections (src/vector.rs:320-327), which are a count and nothing else - a sparse
+    // vector costs what its values cost, as in the reference.
+    struct Run { bool null; uint64_t sections; };
+    std::vector<Run> runs;
+    std::vector<uint8_t> values; // element bytes of the complete value sections, in order
+    std::vector<uint8_t> open;   // the open section (the reference's write_buf), fewer than 256 elements
     uint64_t len;                // elements appended so far, nulls included
-    uint32_t open;               // elements in the open section (the reference's write_buf.len())
     uint32_t null_sections;      // explicit null sections written by append_nulls
-    std::vector<uint8_t> enc;    // scratch for the encoded vector
+    std::vector<uint8_t> enc;    // scratch for the encoded value sections
 };
 
 static void appender_clear(cvec_appender *a) {
+    a->runs.clear();
     a->values.clear();
+    a->open.clear();
     a->len = 0;
-    a->open = 0;
     a->null_sections = 0;
 }
 
-// Encodes the first n_elems values, padded with zeros to total elements, as one vector whose header counts
-// `nulls` explicit null sections; *len receives the size, the bytes go to out if it is large enough.
-static cvec_status appender_encode(cvec_appender *a, uint64_t n_elems, uint64_t total, uint32_t nulls, uint8_t *out,
-                                   size_t cap, size_t *len) {
-    const size_t w = width(a->etype);
-    std::vector<uint8_t> padded;
-    const uint8_t *vals = a->values.data();
-    if (total > n_elems) {
-        padded.assign((size_t)total * w, 0);
-        memcpy(padded.data(), a->values.data(), (size_t)n_elems * w);
-        vals = padded.data();
+static void add_run(std::vector<cvec_appender::Run> &runs, bool null, uint64_t sections) {
+    if (sections == 0) return;
+    if (!runs.empty() && runs.back().null == null) runs.back().sections += sections;
+    else runs.push_back({null, sections});
+}
+
+// The open section has filled up: it becomes a complete value section (encode_section, src/vector.rs:270-281).
+static void close_open(cvec_appender *a) {
+    a->values.insert(a->values.end(), a->open.begin(), a->open.end());
+    a->open.clear();
+    add_run(a->runs, false, 1);
+}
+
+// Size of the section at p (src/section.rs:252-271 and the num_bytes of each kind); 0 if it does not fit in `left`.
+static size_t section_bytes(const uint8_t *p, size_t left, size_t w) {
+    if (left < 1) return 0;
+    size_t n = 0;
+    switch (p[0]) {
+    case 0x00: n = 1; break;                                                           // Null
+    case 0x05: n = 1 + w; break;                                                       // Const
+    case 0x01: if (left < 3) return 0; n = 3 + (size_t)(p[1] | (p[2] << 8)); break;    // NibblePack
+    case 0x03: if (left < 3) return 0; n = 12 + (size_t)(p[1] | (p[2] << 8)); break;   // Delta
+    case 0x06: if (left < 3) return 0; n = (size_t)(p[1] | (p[2] << 8)); break;        // Xor: total incl. header
+    default: return 0;
     }
-    const uint64_t elem_off[2] = {0, total};
+    return n != 0 && n <= left ? n : 0;
+}
+
+// Writes the vector made of `runs` (value sections taken from vals, in order) with the given header counts;
+// *len receives the size, the bytes go to out if it is large enough.
+static cvec_status appender_emit(cvec_appender *a, const std::vector<cvec_appender::Run> &runs, const uint8_t *vals,
+                                 uint64_t value_sections, uint64_t num_elements, uint32_t nulls, uint8_t *out, size_t cap,
+                                 size_t *len) {
+    const size_t w = width(a->etype);
+    const uint64_t n_el = value_sections * FIXED;
+    const uint64_t elem_off[2] = {0, n_el};
     uint64_t byte_off[2] = {0, 0}, total_bytes = 0;
-    a->enc.resize(cvec_max_encoded_bytes(a->etype, 1, total) + 64);
+    a->enc.resize(cvec_max_encoded_bytes(a->etype, 1, n_el) + 64);
     const uint64_t dummy = 0;
-    cvec_status st = cvec_encode_batch(a->etype, total ? (const void *)vals : (const void *)&dummy, elem_off, 1, a->enc.data(),
+    // the value sections as one vector: its bytes behind the 16-byte header are those sections back to back
+    cvec_status st = cvec_encode_batch(a->etype, n_el ? (const void *)vals : (const void *)&dummy, elem_off, 1, a->enc.data(),
                                        a->enc.size(), byte_off, &total_bytes);
     if (st) return st;
     if (total_bytes < HEADER) return CVEC_ERR_HIP;
-    a->enc[12] = (uint8_t)(nulls & 0xffu);
-    a->enc[13] = (uint8_t)((nulls >> 8) & 0xffu);
-    if (len) *len = (size_t)total_bytes;
-    if (out == nullptr || cap < total_bytes) return CVEC_ERR_CAPACITY;
-    memcpy(out, a->enc.data(), (size_t)total_bytes);
+    uint64_t null_bytes = 0;
+    for (const auto &r : runs) if (r.null) null_bytes += r.sections;
+    const uint64_t size = total_bytes + null_bytes;
+    if (len) *len = (size_t)size;
+    if (out == nullptr || cap < size) return CVEC_ERR_CAPACITY;
+    const uint32_t num_bytes = (uint32_t)(size - 4); // BinaryVector.num_bytes (src/vector.rs:54, :139)
+    memset(out, 0, HEADER);
+    memcpy(out, &num_bytes, 4);
+    out[4] = 0x10;                 // VectorType::FixedSection256
+    out[5] = (uint8_t)a->etype;    // VectorSubType
+    const uint32_t ne = (uint32_t)num_elements;
+    memcpy(out + 8, &ne, 4);       // FixedSectStats (src/vector.rs:163-186)
+    out[12] = (uint8_t)(nulls & 0xffu);
+    out[13] = (uint8_t)((nulls >> 8) & 0xffu);
+    const uint8_t *src = a->enc.data() + HEADER, *src_end = a->enc.data() + total_bytes;
+    uint8_t *dst = out + HEADER;
+    for (const auto &r : runs) {
+        if (r.null) {
+            memset(dst, 0, (size_t)r.sections); // NullFixedSect: the byte 0x00 (src/section.rs:440-443)
+            dst += r.sections;
+            continue;
+        }
+        const uint8_t *from = src;
+        for (uint64_t k = 0; k < r.sections; k++) {
+            const size_t n = section_bytes(src, (size_t)(src_end - src), w);
+            if (n == 0) return CVEC_ERR_HIP;
+            src += n;
+        }
+        memcpy(dst, from, (size_t)(src - from));
+        dst += src - from;
+    }
+    if (src != src_end || dst != out + size) return CVEC_ERR_HIP;
     return CVEC_OK;
 }
 
@@ -93,9 +152,16 @@ cvec_status cvec_appender_append(cvec_appender *a, const void *values, size_t n)
     if (!a || (n && !values)) return CVEC_ERR_BAD_ARGUMENT;
     const size_t w = width(a->etype);
     const uint8_t *p = (const uint8_t *)values;
-    a->values.insert(a->values.end(), p, p + n * w);
+    size_t left = n;
+    while (left) {
+        const size_t room = FIXED - a->open.size() / w;
+        const size_t take = left < room ? left : room;
+        a->open.insert(a->open.end(), p, p + take * w);
+        p += take * w;
+        left -= take;
+        if (a->open.size() == FIXED * w) close_open(a);
+    }
     a->len += n;
-    a->open = (uint32_t)((a->open + n) % FIXED);
     return CVEC_OK;
 }
 
@@ -103,17 +169,20 @@ cvec_status cvec_appender_append_nulls(cvec_appender *a, size_t num_nulls) {
     if (!a) return CVEC_ERR_BAD_ARGUMENT;
     // src/vector.rs:311-335: zeros first fill the open section; whole runs of 256 behind an empty write buffer
     // become explicit null sections, counted in the header; what is left opens the next section
+    const size_t w = width(a->etype);
     size_t left = num_nulls;
-    if (left && a->open) {
-        const size_t fill = left < FIXED - a->open ? left : FIXED - a->open;
-        a->open = (uint32_t)((a->open + fill) % FIXED);
+    if (left && !a->open.empty()) {
+        const size_t room = FIXED - a->open.size() / w;
+        const size_t fill = left < room ? left : room;
+        a->open.insert(a->open.end(), fill * w, (uint8_t)0);
         left -= fill;
+        if (a->open.size() == FIXED * w) close_open(a);
     }
-    if (a->open == 0) {
+    if (a->open.empty()) {
+        add_run(a->runs, true, left / FIXED);
         a->null_sections += (uint32_t)(left / FIXED);
-        a->open = (uint32_t)(left % FIXED);
+        a->open.insert(a->open.end(), (left % FIXED) * w, (uint8_t)0);
     }
-    a->values.insert(a->values.end(), num_nulls * width(a->etype), (uint8_t)0);
     a->len += num_nulls;
     return CVEC_OK;
 }
@@ -131,19 +200,39 @@ cvec_status cvec_appender_finish(cvec_appender *a, uint64_t total_num_rows, uint
         if (detail) { detail[0] = total_num_rows; detail[1] = 0xffffffffull; }
         return CVEC_INVALID_NUM_ROWS;
     }
-    // :352-359: the open section is rounded out with zeros, then null sections follow up to total_num_rows
+    // :352-359: the open section is rounded out with zeros, then null sections follow up to total_num_rows.
+    // Built beside the appender's state: a call that fails (out too small) leaves the appender as it was.
+    const size_t w = width(a->etype);
+    std::vector<cvec_appender::Run> runs = a->runs;
+    const uint8_t *vals = a->values.data();
+    std::vector<uint8_t> with_open;
+    uint64_t value_sections = a->values.size() / (FIXED * w);
+    if (!a->open.empty()) {
+        with_open.reserve(a->values.size() + FIXED * w);
+        with_open = a->values;
+        with_open.insert(with_open.end(), a->open.begin(), a->open.end());
+        with_open.resize((size_t)(value_sections + 1) * FIXED * w, 0);
+        vals = with_open.data();
+        value_sections += 1;
+        add_run(runs, false, 1);
+    }
     const uint64_t padded = (a->len + FIXED - 1) / FIXED * FIXED;
     uint32_t nulls = a->null_sections;
-    if (total_num_rows > padded) nulls += (uint32_t)((total_num_rows - padded + FIXED - 1) / FIXED);
-    cvec_status st = appender_encode(a, a->len, total_num_rows, nulls, out, cap, len);
+    if (total_num_rows > padded) {
+        const uint64_t more = (total_num_rows - padded + FIXED - 1) / FIXED;
+        nulls += (uint32_t)more;
+        add_run(runs, true, more);
+    }
+    cvec_status st = appender_emit(a, runs, vals, value_sections, total_num_rows, nulls, out, cap, len);
     if (st == CVEC_OK) appender_clear(a); // :368 reset(); a too-small `out` leaves the appender as it was
     return st;
 }
 
 cvec_status cvec_appender_reader(cvec_appender *a, uint8_t *out, size_t cap, size_t *len) {
     if (!a) return CVEC_ERR_BAD_ARGUMENT;
-    const uint64_t flushed = a->len - a->open; // values in the open section are not in the vector yet (:372-378)
-    return appender_encode(a, flushed, flushed, a->null_sections, out, cap, len);
+    const size_t w = width(a->etype);
+    const uint64_t flushed = a->len - a->open.size() / w; // values in the open section are not in the vector yet (:372-378)
+    return appender_emit(a, a->runs, a->values.data(), a->values.size() / (FIXED * w), flushed, a->null_sections, out, cap, len);
 }
 
 } // extern "C"

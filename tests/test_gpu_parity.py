@@ -376,6 +376,22 @@ def test_mixed_null_appender_bytes_match_oracle(cv, oracle):
     assert a.finish(1000) == o.finish(1000)
 
 
+def test_appender_long_null_runs_are_counts(cv, oracle):
+    """append_nulls far beyond the values (src/vector.rs:320-327: one byte per null section): the handle keeps the
+    runs as counts, the bytes equal the oracle's, readers in between included."""
+    a, o = cv.VectorU32Appender.try_new(64), oracle.Appender(oracle.U32, 64)
+    x = np.arange(1, 1001, dtype=np.uint32) * 3
+    for app in (a, o):
+        app.append_many(x[:300])
+        app.append_nulls(50_000_000)
+        app.append_many(x[300:])
+        app.append_nulls(600)
+    assert a.reader().num_elements() == o.num_elements() - (o.num_elements() % 256)
+    total = 2_000_000_000
+    got, want = a.finish(total), o.finish(total)
+    assert len(got) < 10_000_000 and got == bytes(want)
+
+
 def test_null_section_through_addconst_keeps_base_bits(cv, oracle):
     # src/sink.rs:314-317
     enc = cv.VectorF32XorAppender.try_new(64).encode_all(np.zeros(300, dtype=np.float32))
