@@ -388,9 +388,10 @@ cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_
 
 /* ---- appender handle: VectorAppender<T, W> (src/vector.rs:207-379) ------------------------------ */
 /* What the crate's VectorU32Appender / VectorU64Appender / VectorF32XorAppender do for one vector:
- * values and nulls are appended, finish() returns the vector's bytes.  The handle keeps the appended
- * values, the fill of the open section and the count of explicit null sections on the host (one
- * vector is far below GPU launch granularity); finish() and reader() encode on the GPU and write that
+ * values and nulls are appended, finish() returns the vector's bytes.  The handle keeps the open
+ * section, the values of the complete sections and the runs of explicit null sections (as counts:
+ * append_nulls(n) costs no memory per null section) on the host, one vector being far below GPU launch
+ * granularity; finish() and reader() encode the value sections on the GPU and write the null-section
  * count into the header (num_null_sections, src/vector.rs:160-169, :321-327).  Not thread-safe: one
  * handle per thread, like the reference's &mut self. */
 typedef struct cvec_appender cvec_appender;
