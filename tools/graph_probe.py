@@ -1,40 +1,42 @@
-"""Does replaying the three kernels of a filter step as one HIP graph shorten the step?"""
+#!/usr/bin/env python3
+"""The headline step (index, sections, finalize) launched call by call and replayed from a captured HIP graph of 20
+steps: prints the time per step of both.  The read entry points take their workspace from the caller and neither
+allocate nor synchronise, so they can be captured as they are."""
+import os
 import sys
 import time
-sys.path.insert(0, "/root/repo")
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import compressed_vec_amd as cv
-from compressed_vec_amd import synth
-
-nvec, length = 131072, 2048
-vals = torch.cat([synth.batch_values_torch("f32_xor", 16384, length, v_first=c)[0] for c in range(0, nvec, 16384)])
-eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * length
-b = cv.encode_device("f32", vals, eo)
-raw = nvec * length * 4
-pred = cv.make_pred(cv.F32, 3.0)
-res = b.result_buffer()
-
-
-def timed(fn, iters=50):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / iters
-
-
-t = timed(lambda: b.filter_count_async(pred, result=res))
-print("direct launches: %.4f ms  %.0f GB/s" % (t * 1e3, raw / t / 1e9), flush=True)
+import profile_op
+assert cv.lib().cvec_init(0) == 0
+tname, vals, eo, pred, _ = profile_op.build("cfg5sin")
+batch = cv.encode_device(tname, vals, eo)
+del vals
+res = batch.result_buffer()
+p = cv.make_pred(batch.etype, pred)
+for _ in range(300):
+    batch.filter_count_async(p, result=res)
+torch.cuda.synchronize()
+def timed(fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); fn(n); torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+def plain(n):
+    for _ in range(n):
+        batch.filter_count_async(p, result=res)
+print("plain launches: %.4f ms per step" % min(timed(plain, 200) for _ in range(5)))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
-    b.filter_count_async(pred, result=res)
+    for _ in range(3):
+        batch.filter_count_async(p, result=res)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
-        b.filter_count_async(pred, result=res)
-torch.cuda.synchronize()
-t = timed(g.replay)
-print("graph replay:    %.4f ms  %.0f GB/s  count %d" % (t * 1e3, raw / t / 1e9, int(res[0].item())), flush=True)
+        for _ in range(20):
+            batch.filter_count_async(p, result=res)
+def replay(n):
+    for _ in range(n // 20):
+        g.replay()
+print("graph of 20 steps: %.4f ms per step" % min(timed(replay, 200) for _ in range(5)))
+print("count", int(res.cpu()[0]))
