@@ -174,6 +174,25 @@ __global__ __launch_bounds__(SER_THREADS) void k_ser_stage(uint64_t n, const U *
     if (lane == 0 && c) fill[v] = nf;
 }
 
+// The same for a scrape of a few values per series: one lane per series (a wave per series would move one value).
+template <class U>
+__global__ void k_ser_stage_few(uint64_t n, const U *__restrict__ values, uint64_t per_vector, U *__restrict__ stage,
+                                uint32_t *__restrict__ fill) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t base = v * per_vector, c = per_vector;
+    const uint32_t f = fill[v];
+    const uint64_t tot = f + c, closed = tot / FIXED_LEN * FIXED_LEN;
+    const uint32_t nf = (uint32_t)(tot - closed);
+    U *row = stage + v * FIXED_LEN;
+    if (closed == 0) {
+        for (uint64_t i = f; i < tot; i++) row[i] = values ? values[base + (i - f)] : (U)0;
+    } else {
+        for (uint32_t i = 0; i < nf; i++) row[i] = values ? values[base + (closed - f) + i] : (U)0;
+    }
+    fill[v] = nf;
+}
+
 __global__ void k_ser_max_len(uint64_t n, const uint64_t *__restrict__ len, unsigned long long *__restrict__ out) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t x = v < n ? len[v] : 0;
@@ -298,6 +317,8 @@ struct cvec_series_appender {
     Arena arena;
     std::vector<Segment> segs;
     std::vector<Segment> tail;           // finish()'s closing segments (open section, null run), between seal and emit
+    bool uniform = true;                 // every call since the last reset gave all series the same count:
+    uint32_t ufill = 0;                  // ... then all open sections hold ufill values and the host needs no read-back
     int sealed = 0;                      // 0 open, 1 sealed for finish, 2 sealed for reader
     uint64_t sealed_rows = 0, sealed_bytes = 0, sealed_sections = 0;
     uint64_t resident_bytes = 0;
@@ -330,6 +351,8 @@ cvec_status clear_state(cvec_series_appender *a, hipStream_t st) {
     a->tail.clear();
     a->arena.rewind();
     a->sealed = 0;
+    a->uniform = true;
+    a->ufill = 0;
     a->resident_bytes = 0;
     return CVEC_OK;
 }
@@ -363,12 +386,15 @@ cvec_status encode_segment(cvec_series_appender *a, const void *vals, const uint
 }
 
 // Keeps the counts in a->run as a segment of null sections if any series has one.
-cvec_status null_run_segment(cvec_series_appender *a, std::vector<Segment> *to, hipStream_t st) {
+// `known` >= 0: the sum of the counts, which the host already knows (uniform calls).
+cvec_status null_run_segment(cvec_series_appender *a, std::vector<Segment> *to, hipStream_t st, int64_t known = -1) {
     const uint64_t n = a->n;
-    SER_TRY(launch_exclusive_scan(a->run.as<uint64_t>(), n, a->run_scan.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
-    uint64_t total = 0;
-    SER_TRY(hipMemcpyAsync(&total, a->run_scan.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    SER_TRY(hipStreamSynchronize(st));
+    uint64_t total = (uint64_t)known;
+    if (known < 0) {
+        SER_TRY(launch_exclusive_scan(a->run.as<uint64_t>(), n, a->run_scan.as<uint64_t>(), a->scan_tmp.as<uint64_t>(), st));
+        SER_TRY(hipMemcpyAsync(&total, a->run_scan.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+        SER_TRY(hipStreamSynchronize(st));
+    }
     if (total == 0) return CVEC_OK;
     Segment s;
     SER_TRY(a->arena.take(n * 8, (void **)&s.null_run));
@@ -387,17 +413,35 @@ cvec_status append_t(cvec_series_appender *a, const void *d_values, const uint64
     uint64_t *cnt = a->cnt.as<uint64_t>(), *off = a->off.as<uint64_t>();
     k_ser_plan<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, d_elem_off, per_vector, nulls_mode, a->fill.as<uint32_t>(),
                                                        a->len.as<uint64_t>(), a->nulls.as<uint32_t>(), cnt, a->run.as<uint64_t>());
-    SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
+    // A scrape gives every series the same number of values: as long as all calls did, the host knows every
+    // series' fill and with it what this call completes, and the counts need not be read back.
+    if (d_elem_off != nullptr) a->uniform = false;
     uint64_t total = 0;
-    SER_TRY(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
-    SER_TRY(hipStreamSynchronize(st));
+    int64_t known_run = -1;
+    if (a->uniform) {
+        const uint64_t tot = (uint64_t)a->ufill + per_vector, sections = tot / FIXED_LEN;
+        uint64_t flush = sections * FIXED_LEN;
+        if (nulls_mode) flush = (a->ufill != 0 && sections != 0) ? FIXED_LEN : 0; // as k_ser_plan
+        total = n * flush;
+        known_run = (int64_t)(nulls_mode ? n * (sections - flush / FIXED_LEN) : 0);
+        a->ufill = (uint32_t)(tot % FIXED_LEN);
+        if (total) SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
+    } else {
+        SER_TRY(launch_exclusive_scan(cnt, n, off, a->scan_tmp.as<uint64_t>(), st));
+        SER_TRY(hipMemcpyAsync(&total, off + n, 8, hipMemcpyDeviceToHost, st));
+        SER_TRY(hipStreamSynchronize(st));
+    }
     if (total) {
         SER_TRY(a->vals.need(total * sizeof(U)));
         k_ser_flush<U><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, (const U *)d_values, d_elem_off, per_vector,
                                                                a->stage.as<U>(), a->fill.as<uint32_t>(), off, a->vals.as<U>());
     }
-    k_ser_stage<U><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, (const U *)d_values, d_elem_off, per_vector, a->stage.as<U>(),
-                                                           a->fill.as<uint32_t>());
+    if (d_elem_off == nullptr && per_vector <= 8)
+        k_ser_stage_few<U><<<lane_blocks(n), SER_THREADS, 0, st>>>(n, (const U *)d_values, per_vector, a->stage.as<U>(),
+                                                                   a->fill.as<uint32_t>());
+    else
+        k_ser_stage<U><<<wave_blocks(n), SER_THREADS, 0, st>>>(n, (const U *)d_values, d_elem_off, per_vector, a->stage.as<U>(),
+                                                               a->fill.as<uint32_t>());
     SER_TRY(hipGetLastError());
     if (total) {
         Segment s;
@@ -408,7 +452,7 @@ cvec_status append_t(cvec_series_appender *a, const void *d_values, const uint64
     } else {
         SER_TRY(hipStreamSynchronize(st)); // the caller's values may be reused when the call returns
     }
-    if (nulls_mode) return null_run_segment(a, &a->segs, st); // behind the section that the zeros completed
+    if (nulls_mode) return null_run_segment(a, &a->segs, st, known_run); // behind the section that the zeros completed
     return CVEC_OK;
 }
 

@@ -82,7 +82,7 @@ def main():
                         if counts[v]:
                             o.append_many(vals[off[v]:off[v + 1]])
                 elif op == 2:                                 # a scrape: k values for every series
-                    k = int(rng.integers(1, 600))
+                    k = int(rng.integers(1, 600)) if rng.random() < 0.5 else int(rng.integers(1, 9))
                     block = np.stack([values(rng, tname, k) for _ in range(n)])
                     app.append(block)
                     for v, o in enumerate(oracles):
@@ -95,7 +95,7 @@ def main():
                         if counts[v]:
                             o.append_nulls(int(counts[v]))
                 elif op == 4:                                 # uniform nulls
-                    k = int([1, 255, 256, 257, 512, 100_000][int(rng.integers(0, 6))])
+                    k = int([1, 3, 255, 256, 257, 512, 100_000][int(rng.integers(0, 7))])
                     app.append_nulls(k)
                     for o in oracles:
                         o.append_nulls(k)
