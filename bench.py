@@ -382,6 +382,35 @@ def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
     t = _time_gpu(torch, lambda: indexed.filter_count_async(pred, result=res), 40)
     ex["filter_resident_index_GBs"] = round(raw_bytes / t / 1e9, 2)
     ex["filter_resident_index_same_count"] = bool(int(res.cpu()[0]) == int(batch.filter_count_async(pred).cpu()[0]))
+    # ingest through the series appender: the same values arrive as scrapes of 64 per vector, sections are encoded as
+    # they complete, finish() must give the batch that encode_all gave
+    n_vec, vec_len, k = batch.n_vectors, values.numel() // batch.n_vectors, 64
+    mat = values.view(n_vec, vec_len)
+    blocks = [mat[:, c0:c0 + k].contiguous() for c0 in range(0, vec_len, k)]
+    app = cv.SeriesAppender("f32", n_vec)
+    for rep in range(2):                                   # the first fill sizes the handle's buffers
+        t_plain, t_flush = [], []
+        for blk in blocks:
+            before = app.stats()["segments"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            app.append(blk)
+            torch.cuda.synchronize()
+            (t_flush if app.stats()["segments"] > before else t_plain).append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        fin = app.finish(vec_len)
+        torch.cuda.synchronize()
+        t_fin = time.perf_counter() - t0
+    ex["series_appender"] = {
+        "series": n_vec, "values_per_scrape": k,
+        "scrape_ms": round(1e3 * sum(t_plain) / max(len(t_plain), 1), 4),
+        "scrape_completing_a_section_ms": round(1e3 * sum(t_flush) / max(len(t_flush), 1), 4),
+        "finish_ms": round(1e3 * t_fin, 3),
+        "ingest_and_finish_GBs": round(raw_bytes / (sum(t_plain) + sum(t_flush) + t_fin) / 1e9, 2),
+        "equals_encode_all": bool(fin.n_bytes == batch.n_bytes and torch.equal(fin.d_bytes[:fin.n_bytes], batch.d_bytes[:batch.n_bytes])
+                                  and torch.equal(fin.d_byte_off, batch.d_byte_off))}
+    del app, fin, blocks, mat
+    torch.cuda.empty_cache()
     # host-inclusive: inputs start and results end in page-locked host memory; the library pipelines
     # chunks of vectors through three device slots (copy-in, kernels and copy-out overlap)
     from compressed_vec_amd import hostpath
