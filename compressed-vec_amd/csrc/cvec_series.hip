@@ -67,7 +67,7 @@ struct Segment { // the arrays live in the handle's arena
 struct Arena {
     struct Slab { uint8_t *p; size_t cap, used; };
     std::vector<Slab> slabs;
-    static constexpr size_t SLAB_MIN = (size_t)4 << 20, SLAB_MAX = (size_t)256 << 20;
+    static constexpr size_t SLAB_MIN = (size_t)4 << 20, SLAB_MAX = (size_t)1 << 30;
     ~Arena() { release(); }
     void release() {
         for (Slab &s : slabs) (void)hipFree(s.p);
@@ -88,6 +88,20 @@ struct Arena {
         slabs.push_back(s);
         *out = s.p;
         return hipSuccess;
+    }
+    // Room for `bytes` in a slab that exists already, or nullptr: for an allocation whose final size is not
+    // known yet (trim() gives back what it did not need).
+    void *take_if_room(size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        for (Slab &s : slabs)
+            if (s.cap - s.used >= bytes) { void *p = s.p + s.used; s.used += bytes; return p; }
+        return nullptr;
+    }
+    // The most recent allocation of its slab shrinks to `bytes`.
+    void trim(void *p, size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        for (Slab &s : slabs)
+            if ((uint8_t *)p >= s.p && (uint8_t *)p < s.p + s.used) { s.used = (size_t)((uint8_t *)p - s.p) + bytes; return; }
     }
     size_t reserved() const { size_t t = 0; for (const Slab &s : slabs) t += s.cap; return t; }
 };
@@ -200,7 +214,14 @@ __global__ void k_ser_max_len(uint64_t n, const uint64_t *__restrict__ len, unsi
         const uint64_t y = __shfl_xor(x, d);
         x = y > x ? y : x;
     }
-    if ((threadIdx.x & 63) == 0 && x) atomicMax(out, (unsigned long long)x);
+    // one atomic per workgroup: atomics on one address complete one after the other
+    __shared__ uint64_t s_max[SER_WAVES];
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < SER_WAVES; w++) x = s_max[w] > x ? s_max[w] : x;
+        if (x) atomicMax(out, (unsigned long long)x);
+    }
 }
 
 // One lane per series: elements of the closing segment (open section + zeros up to total_rows).
@@ -363,24 +384,34 @@ cvec_status encode_segment(cvec_series_appender *a, const void *vals, const uint
     const uint64_t n = a->n;
     const size_t cap = cvec_max_encoded_bytes(a->etype, n, total);
     const size_t wsb = encode_workspace_bytes(n, total);
-    SER_TRY(a->enc_bytes.need(cap + 256));
-    SER_TRY(a->enc_off.need((n + 1) * 8));
     SER_TRY(a->enc_sec.need((n + 1) * 8));
     SER_TRY(a->enc_res.need(CVEC_RESULT_WORDS * 8));
     SER_TRY(a->enc_ws.need(wsb));
-    SER_TRY(launch_encode(a->etype, vals, off, n, total, a->enc_bytes.as<uint8_t>(), cap, a->enc_off.as<uint64_t>(),
-                          a->enc_sec.as<uint64_t>(), a->enc_res.as<uint64_t>(), a->enc_ws.p, wsb, st));
+    Segment s;
+    SER_TRY(a->arena.take((n + 1) * 8, (void **)&s.off));
+    // The encoder writes straight into the arena when a slab has room for the worst case (what the section bytes
+    // did not need goes back); otherwise into a scratch buffer, and the arena gets a copy of the exact size.
+    uint8_t *direct = (uint8_t *)a->arena.take_if_room(cap + 256);
+    uint8_t *dst = direct;
+    if (!direct) {
+        SER_TRY(a->enc_bytes.need(cap + 256));
+        dst = a->enc_bytes.as<uint8_t>();
+    }
+    SER_TRY(launch_encode(a->etype, vals, off, n, total, dst, cap, s.off, a->enc_sec.as<uint64_t>(), a->enc_res.as<uint64_t>(),
+                          a->enc_ws.p, wsb, st));
     uint64_t n_bytes = 0;
     SER_TRY(hipMemcpyAsync(&n_bytes, a->enc_res.p, 8, hipMemcpyDeviceToHost, st));
-    SER_TRY(hipStreamSynchronize(st));
+    SER_TRY(hipStreamSynchronize(st)); // also: the encode buffers are reused by the next call, whatever its stream
     if (n_bytes < n * HEADER_BYTES || n_bytes > cap) return CVEC_ERR_HIP;
-    Segment s;
-    SER_TRY(a->arena.take(n_bytes + 16, (void **)&s.bytes));
-    SER_TRY(a->arena.take((n + 1) * 8, (void **)&s.off));
+    if (direct) {
+        a->arena.trim(direct, n_bytes + 16);
+        s.bytes = direct;
+    } else {
+        SER_TRY(a->arena.take(n_bytes + 16, (void **)&s.bytes));
+        SER_TRY(hipMemcpyAsync(s.bytes, dst, n_bytes, hipMemcpyDeviceToDevice, st));
+        SER_TRY(hipStreamSynchronize(st));
+    }
     s.n_bytes = n_bytes;
-    SER_TRY(hipMemcpyAsync(s.bytes, a->enc_bytes.p, n_bytes, hipMemcpyDeviceToDevice, st));
-    SER_TRY(hipMemcpyAsync(s.off, a->enc_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
-    SER_TRY(hipStreamSynchronize(st)); // the encode buffers are reused by the next call, whatever its stream
     *seg = s;
     return CVEC_OK;
 }
