@@ -109,6 +109,7 @@ SIGNATURES = {
     "cvec_series_appender_free": (None, [C.c_void_p]),
     "cvec_series_appender_reset": (C.c_int32, [C.c_void_p]),
     "cvec_series_appender_append_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "cvec_series_appender_append_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "cvec_series_appender_append_nulls_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "cvec_series_appender_seal": (C.c_int32, [C.c_void_p, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64),
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]),

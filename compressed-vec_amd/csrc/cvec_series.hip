@@ -335,6 +335,7 @@ struct cvec_series_appender {
     Buf run, run_scan;                   // per call: null sections per series that are kept as a count, their scan
     Buf enc_bytes, enc_off, enc_sec, enc_res, enc_ws;
     Buf out_size, out_off, out_nsec, out_sec, tab_off, tab_bytes, tab_null, maxlen;
+    Buf up_vals, up_off;                 // device copies of host arguments (the *_host calls)
     Arena arena;
     std::vector<Segment> segs;
     std::vector<Segment> tail;           // finish()'s closing segments (open section, null run), between seal and emit
@@ -551,6 +552,34 @@ cvec_status cvec_series_appender_append_dev(cvec_series_appender *a, const void 
                                             uint64_t per_series, void *stream) {
     if (a && !d_values && (d_elem_off || per_series)) return CVEC_ERR_BAD_ARGUMENT;
     return append_any(a, d_values, d_elem_off, per_series, 0, stream);
+}
+
+cvec_status cvec_series_appender_append_host(cvec_series_appender *a, const void *h_values, const uint64_t *h_elem_off,
+                                             uint64_t per_series, void *stream) {
+    if (!a) return CVEC_ERR_BAD_ARGUMENT;
+    if (a->sealed) return CVEC_ERR_BAD_ARGUMENT;
+    const uint64_t n = a->n;
+    if (n == 0) return CVEC_OK;
+    uint64_t total = n * per_series;
+    if (h_elem_off) {
+        for (uint64_t v = 0; v < n; v++)
+            if (h_elem_off[v + 1] < h_elem_off[v]) return CVEC_ERR_BAD_ARGUMENT;
+        if (h_elem_off[0] != 0) return CVEC_ERR_BAD_ARGUMENT;
+        total = h_elem_off[n];
+    }
+    if (total == 0) return CVEC_OK;
+    if (!h_values) return CVEC_ERR_BAD_ARGUMENT;
+    DeviceScope scope(a->device);
+    hipStream_t st = (hipStream_t)stream;
+    SER_TRY(a->up_vals.need(total * a->width));
+    SER_TRY(hipMemcpyAsync(a->up_vals.p, h_values, total * a->width, hipMemcpyHostToDevice, st));
+    const uint64_t *d_off = nullptr;
+    if (h_elem_off) {
+        SER_TRY(a->up_off.need((n + 1) * 8));
+        SER_TRY(hipMemcpyAsync(a->up_off.p, h_elem_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+        d_off = a->up_off.as<uint64_t>();
+    }
+    return append_any(a, a->up_vals.p, d_off, per_series, 0, stream); // synchronises on the stream before it returns
 }
 
 cvec_status cvec_series_appender_append_nulls_dev(cvec_series_appender *a, const uint64_t *d_elem_off, uint64_t per_series,

@@ -53,6 +53,25 @@ class SeriesAppender:
                 keep = t if t.numel() else torch.zeros(4, dtype=t.dtype, device=self.device)
                 N.check(N.lib().cvec_series_appender_append_dev(self._h, _ptr(keep), _ptr(eo), 0, _stream_ptr()))
 
+    def append_host(self, values, elem_off=None):
+        """append for values in host memory (numpy): n_series x k, or 1-D with elem_off (uint64[n_series + 1], from 0).
+        The library copies them to the device itself."""
+        arr = np.ascontiguousarray(values)
+        if arr.dtype.itemsize != (8 if self.etype == N.U64 else 4) or (arr.dtype.kind == "f") != (self.etype == N.F32):
+            raise N.CodingError(N.ERR_BAD_ARGUMENT, "values must have the appender's element type")
+        with torch.cuda.device(self.device):
+            if elem_off is None:
+                if arr.ndim != 2 or arr.shape[0] != self.n_series:
+                    raise N.CodingError(N.ERR_BAD_ARGUMENT, "values must be n_series x k")
+                N.check(N.lib().cvec_series_appender_append_host(self._h, arr.ctypes.data_as(C.c_void_p), None, int(arr.shape[1]),
+                                                                 _stream_ptr()))
+            else:
+                eo = np.ascontiguousarray(elem_off, dtype=np.uint64)
+                if eo.size != self.n_series + 1 or int(eo[-1]) > arr.size:
+                    raise N.CodingError(N.ERR_BAD_ARGUMENT, "elem_off must hold n_series + 1 offsets within the values")
+                N.check(N.lib().cvec_series_appender_append_host(self._h, arr.ctypes.data_as(C.c_void_p),
+                                                                 eo.ctypes.data_as(C.c_void_p), 0, _stream_ptr()))
+
     def _offsets(self, elem_off, limit=None):
         eo = torch.as_tensor(elem_off, dtype=torch.int64)
         if eo.numel() != self.n_series + 1 or bool((eo[1:] < eo[:-1]).any()) or int(eo[0]) < 0:

@@ -434,6 +434,10 @@ cvec_status cvec_series_appender_reset(cvec_series_appender *a);                
  * n_series x per_series row-major.  Element type of the handle, device memory. */
 cvec_status cvec_series_appender_append_dev(cvec_series_appender *a, const void *d_values,
                                             const uint64_t *d_elem_off /*nullable*/, uint64_t per_series, void *stream);
+/* The same with values (and offsets, starting at 0) in host memory: copied to the device, then appended.
+ * Page-locked memory makes the copy asynchronous up to the call's own synchronisation. */
+cvec_status cvec_series_appender_append_host(cvec_series_appender *a, const void *h_values,
+                                             const uint64_t *h_elem_off /*nullable*/, uint64_t per_series, void *stream);
 /* append_nulls (src/vector.rs:311-335): series v receives d_elem_off[v+1] - d_elem_off[v] nulls, or
  * per_series with d_elem_off == NULL.  Zeros first fill the open section; whole runs of 256 behind an empty
  * open section are explicit null sections, counted in the header. */

@@ -194,3 +194,33 @@ def test_series_appender_long_null_runs_cost_a_count_not_their_length(cv, oracle
     batch = app.finish(total)
     assert batch.n_sections == n * ((total + 255) // 256)
     _same_vectors(batch.download(), oracles, total=total)
+
+
+def test_series_appender_host_values_equal_device_values(cv, oracle):
+    """cvec_series_appender_append_host: the same calls with the values in host memory."""
+    rng = np.random.default_rng(31)
+    n = 23
+    dev, host = cv.SeriesAppender("u32", n), cv.SeriesAppender("u32", n)
+    oracles = [oracle.Appender(oracle.U32, 64) for _ in range(n)]
+    for step in range(6):
+        if step % 2 == 0:
+            block = rng.integers(0, 1 << 20, size=(n, int(rng.integers(1, 400)))).astype(np.uint32)
+            dev.append(block)
+            host.append_host(block)
+            for v, o in enumerate(oracles):
+                o.append_many(block[v])
+        else:
+            counts = rng.integers(0, 500, size=n)
+            off = np.zeros(n + 1, dtype=np.uint64)
+            off[1:] = np.cumsum(counts)
+            vals = rng.integers(0, 1 << 31, size=int(off[-1])).astype(np.uint32)
+            dev.append(vals, off.astype(np.int64))
+            host.append_host(vals, off)
+            for v, o in enumerate(oracles):
+                o.append_many(vals[int(off[v]):int(off[v + 1])])
+    with pytest.raises(cv.CodingError):
+        host.append_host(np.zeros(3, np.uint32), np.array([0, 2, 1] + [3] * (n - 2), dtype=np.uint64))   # offsets go down
+    total = max(o.num_elements() for o in oracles)
+    a, b = dev.finish(total).download(), host.finish(total).download()
+    _same_vectors(a, oracles, total=total)
+    assert all(a.vector(v) == b.vector(v) for v in range(n))
