@@ -85,13 +85,17 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_stream_index(int kind, const
     uint4 pre[IDX_PRE_REGS];
     bool have_pre = false;
     // squares a jump table: dst[r] = src[src[r]]
+    // (all first reads, then all second reads, then the writes: written per entry, the two dependent reads of
+    // every entry wait for each other in turn, 36 LDS round trips per table instead of two)
     auto hop = [&](const uint16_t *src, uint16_t *dst) {
+        constexpr int K = IDX_EXT / 64;
+        uint32_t m[K], v[K];
 #pragma unroll
-        for (int k = 0; k < IDX_EXT / 64; k++) {
-            const uint32_t r = 64 * k + lane;
-            const uint32_t m = src[r];
-            dst[r] = m == IDX_NONE ? (uint16_t)IDX_NONE : src[m];
-        }
+        for (int k = 0; k < K; k++) m[k] = src[64 * k + lane];
+#pragma unroll
+        for (int k = 0; k < K; k++) v[k] = src[m[k] == IDX_NONE ? 0u : m[k]];
+#pragma unroll
+        for (int k = 0; k < K; k++) dst[64 * k + lane] = m[k] == IDX_NONE ? (uint16_t)IDX_NONE : (uint16_t)v[k];
     };
     auto stage = [&]() {
         tile_base = p & ~15ull;
@@ -111,15 +115,21 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_stream_index(int kind, const
         have_pre = true;
         const uint64_t left = end - tile_base; // p < end here
         const uint32_t end_rel = left < 0xffffu ? (uint32_t)left : 0xffffu;
+        {   // one octet ahead; both bytes of every position are read before any of them is used
+            constexpr int K = IDX_EXT / 64;
+            uint32_t mk[K], wd[K];
 #pragma unroll
-        for (int k = 0; k < IDX_EXT / 64; k++) { // one octet ahead
-            const uint32_t r = 64 * k + lane;
-            uint32_t nx = IDX_NONE;
-            if (r < IDX_TILE) {
-                const uint32_t e = r + octet_size(tile[r], tile[r + 1]);
-                if (e <= end_rel) nx = e; // the octet lies inside the stream
+            for (int k = 0; k < K; k++) {
+                const uint32_t r = 64 * k + lane;
+                mk[k] = tile[r];
+                wd[k] = tile[r + 1 < IDX_EXT ? r + 1 : r];
             }
-            ja[r] = (uint16_t)nx;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t r = 64 * k + lane;
+                const uint32_t e = r + octet_size(mk[k], wd[k]);
+                ja[r] = (uint16_t)((r < IDX_TILE && e <= end_rel) ? e : IDX_NONE); // the octet lies inside the stream
+            }
         }
         hop(ja, jb); // 2
         hop(jb, ja); // 4
