@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_stream_index(int kind, const
     // (all first reads, then all second reads, then the writes: written per entry, the two dependent reads of
     // every entry wait for each other in turn, 36 LDS round trips per table instead of two)
     auto hop = [&](const uint16_t *src, uint16_t *dst) {
-        constexpr int K = IDX_EXT / 64;
+        constexpr int K = IDX_TILE / 64; // entries from IDX_TILE on are IDX_NONE in every table (set once, below)
         uint32_t m[K], v[K];
 #pragma unroll
         for (int k = 0; k < K; k++) m[k] = src[64 * k + lane];
@@ -116,25 +116,27 @@ __global__ __launch_bounds__(64 * IDX_WAVES) void k_stream_index(int kind, const
         const uint64_t left = end - tile_base; // p < end here
         const uint32_t end_rel = left < 0xffffu ? (uint32_t)left : 0xffffu;
         {   // one octet ahead; both bytes of every position are read before any of them is used
-            constexpr int K = IDX_EXT / 64;
+            constexpr int K = IDX_TILE / 64;
             uint32_t mk[K], wd[K];
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const uint32_t r = 64 * k + lane;
                 mk[k] = tile[r];
-                wd[k] = tile[r + 1 < IDX_EXT ? r + 1 : r];
+                wd[k] = tile[r + 1];
             }
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const uint32_t r = 64 * k + lane;
                 const uint32_t e = r + octet_size(mk[k], wd[k]);
-                ja[r] = (uint16_t)((r < IDX_TILE && e <= end_rel) ? e : IDX_NONE); // the octet lies inside the stream
+                ja[r] = (uint16_t)(e <= end_rel ? e : IDX_NONE); // the octet lies inside the stream
             }
         }
         hop(ja, jb); // 2
         hop(jb, ja); // 4
         hop(ja, jb); // 8 octets ahead
     };
+    // positions behind the tile start no octet that the tables cover: constant in both tables
+    for (uint32_t r = IDX_TILE + lane; r < IDX_EXT; r += 64) { ja[r] = (uint16_t)IDX_NONE; jb[r] = (uint16_t)IDX_NONE; }
     uint64_t blk = 0, blk_start = p, o = 0;
     bool staged = false;
     while (o < noct && st == CVEC_OK) {
