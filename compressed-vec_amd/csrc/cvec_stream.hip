@@ -262,6 +262,52 @@ __global__ __launch_bounds__(256) void k_stream_scan_write(const uint64_t *__res
     if (KIND == CVEC_STREAM_F64_XOR && first == 0 && lane == 0) out[elem_off[s]] = carries[blk]; // the raw first value
 }
 
+// The same with one wave per stream, which walks the stream's blocks in order and carries the running state in a
+// register: no block totals, no carries, the raw values are read once.  For batches of many streams (the
+// launcher decides); a batch of a few long streams has too few waves for this and takes the three kernels above.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_stream_scan_serial(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ byte_off,
+                                                            const uint64_t *__restrict__ raw, const uint64_t *__restrict__ blk_base,
+                                                            const uint64_t *__restrict__ elem_off, uint64_t n,
+                                                            const int32_t *__restrict__ status, uint64_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n) return;
+    if (status[s] != CVEC_OK) return;
+    const uint64_t b0 = blk_base[s], b1 = blk_base[s + 1];
+    if (b0 == b1) return; // k_stream_finish wrote what such a stream holds
+    const uint64_t nval = elem_off[s + 1] - elem_off[s];
+    const uint64_t shift = KIND == CVEC_STREAM_F64_XOR ? 1 : 0;
+    uint64_t acc = 0;
+    if (KIND == CVEC_STREAM_F64_XOR) {
+        acc = *(const u64u *)(bytes + byte_off[s]); // the raw first value
+        if (lane == 0) out[elem_off[s]] = acc;
+    }
+    const uint4 *p = (const uint4 *)(raw + b0 * FIXED_LEN + 4 * lane);
+    uint4 a = p[0], b = p[1];
+    for (uint64_t blk = b0; blk < b1; blk++) {
+        uint4 na = a, nb = b;
+        if (blk + 1 < b1) { // the next block's values are on their way while this one is scanned and written
+            const uint4 *q = (const uint4 *)(raw + (blk + 1) * FIXED_LEN + 4 * lane);
+            na = q[0]; nb = q[1];
+        }
+        uint64_t x[4] = {((uint64_t)a.y << 32) | a.x, ((uint64_t)a.w << 32) | a.z, ((uint64_t)b.y << 32) | b.x,
+                         ((uint64_t)b.w << 32) | b.z};
+        x[1] = comb<KIND>(x[0], x[1]); x[2] = comb<KIND>(x[1], x[2]); x[3] = comb<KIND>(x[2], x[3]);
+        const uint64_t incl = wave_scan_incl<KIND>(x[3], lane);
+        uint64_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 0;
+        const uint64_t base = comb<KIND>(acc, excl);
+        const uint64_t first = (blk - b0) * FIXED_LEN; // index among the packed values
+        uint64_t *o = out + elem_off[s] + shift + first + 4 * lane;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (shift + first + 4 * lane + i < nval) o[i] = comb<KIND>(base, x[i]);
+        acc = comb<KIND>(acc, __shfl(incl, 63, 64));
+        a = na; b = nb;
+    }
+}
+
 // A stream without any packed value (XOR stream of one value) has no block: its first value is
 // written here; also folds the statuses into the result block.
 template <int KIND>
@@ -314,6 +360,11 @@ size_t stream_unpack_workspace_bytes(uint64_t n_streams, uint64_t n_values_total
     return carve_unpack(nullptr, n_streams, max_blocks_of(n_streams, n_values_total)).total;
 }
 
+#ifndef CVEC_STREAM_SERIAL_MIN
+#define CVEC_STREAM_SERIAL_MIN 2048
+#endif
+constexpr uint64_t STREAM_SERIAL_MIN = CVEC_STREAM_SERIAL_MIN;
+
 template <int KIND>
 static hipError_t unpack_t(const uint8_t *d_bytes, const uint64_t *d_byte_off, uint64_t n_bytes,
                            const uint64_t *d_elem_off, uint64_t n, uint64_t n_values_total, uint64_t *d_out,
@@ -334,11 +385,19 @@ static hipError_t unpack_t(const uint8_t *d_bytes, const uint64_t *d_byte_off, u
     e = launch_raw_blocks_u64(d_bytes, w.desc, maxb, w.sec_res, w.raw, stream);
     if (e != hipSuccess) return e;
     const uint32_t gb = (uint32_t)((maxb + 3) / 4);
-    k_stream_totals<KIND><<<gb, 256, 0, stream>>>(w.raw, maxb, w.totals);
-    k_stream_carries<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, n, d_status, w.totals, w.carries);
+    // enough streams for a wave each to fill the chip (256 CUs x 8 waves): one pass over the raw values
+    const bool serial = n >= STREAM_SERIAL_MIN;
+    if (!serial) {
+        k_stream_totals<KIND><<<gb, 256, 0, stream>>>(w.raw, maxb, w.totals);
+        k_stream_carries<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, n, d_status, w.totals, w.carries);
+    }
     k_stream_finish<KIND><<<g, 256, 0, stream>>>(d_bytes, d_byte_off, w.blk_base, d_elem_off, n, w.sec_res, d_status, d_out,
                                                  d_result);
-    k_stream_scan_write<KIND><<<gb, 256, 0, stream>>>(w.raw, w.blk_base, w.blk_stream, d_elem_off, n, maxb, w.carries, d_status, d_out);
+    if (serial)
+        k_stream_scan_serial<KIND><<<(uint32_t)((n + 3) / 4), 256, 0, stream>>>(d_bytes, d_byte_off, w.raw, w.blk_base, d_elem_off, n,
+                                                                                d_status, d_out);
+    else
+        k_stream_scan_write<KIND><<<gb, 256, 0, stream>>>(w.raw, w.blk_base, w.blk_stream, d_elem_off, n, maxb, w.carries, d_status, d_out);
     return hipGetLastError();
 }
 

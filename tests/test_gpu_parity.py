@@ -1178,3 +1178,40 @@ def test_pipeline_error_exit_drains_and_the_next_call_is_clean(cv, oracle, monke
     with pytest.raises(cv.CodingError) as e:
         cv.decode_host(host, out=small, return_status=True)
     assert e.value.code == N.ERR_CAPACITY
+
+
+def test_legacy_streams_many_short_streams_vs_oracle(cv, oracle):
+    """Batches of thousands of streams take the one-pass scan (a wave per stream, the running sum / XOR carried from
+    block to block): ragged lengths around the 256-value block size, empty streams, against the oracle's packers and
+    the values themselves."""
+    from compressed_vec_amd import stream
+    rng = np.random.default_rng(41)
+    n = 2600
+    lens = rng.integers(0, 900, size=n)
+    lens[::97] = 0
+    lens[1::97] = 256
+    lens[2::97] = 257
+    eo = np.zeros(n + 1, dtype=np.uint64)
+    eo[1:] = np.cumsum(lens)
+    total = int(eo[-1])
+    inc = rng.integers(0, 1 << 20, size=total).astype(np.uint64)
+    inc[rng.random(total) < 0.3] = 0
+    u = np.concatenate([np.cumsum(inc[int(eo[s]):int(eo[s + 1])]) for s in range(n)] + [np.zeros(0, np.uint64)]).astype(np.uint64)
+    blob, bo, st = stream.pack_batch("u64_delta", u, eo)
+    assert not st.any()
+    for s in range(0, n, 131):
+        assert blob[int(bo[s]):int(bo[s + 1])].tobytes() == bytes(oracle.pack_u64_delta(u[int(eo[s]):int(eo[s + 1])]))
+    got, st = stream.unpack_batch("u64_delta", blob, bo, eo)
+    assert not st.any() and np.array_equal(got, u)
+    # f64 XOR: a stream needs at least one value
+    lens_f = np.maximum(lens, 1)
+    eof = np.zeros(n + 1, dtype=np.uint64)
+    eof[1:] = np.cumsum(lens_f)
+    f = (rng.standard_normal(int(eof[-1])) * 1e3).astype(np.float64)
+    f[rng.random(f.size) < 0.2] = 0.0
+    blob, bo, st = stream.pack_batch("f64_xor", f, eof)
+    assert not st.any()
+    for s in range(0, n, 131):
+        assert blob[int(bo[s]):int(bo[s + 1])].tobytes() == bytes(oracle.pack_f64_xor(f[int(eof[s]):int(eof[s + 1])]))
+    got, st = stream.unpack_batch("f64_xor", blob, bo, eof)
+    assert not st.any() and np.array_equal(np.asarray(got).view(np.uint64), f.view(np.uint64))
