@@ -470,7 +470,7 @@ static ReadWs carve_read_ws(void *base, uint64_t n_vectors, uint64_t n_sections)
     w.vstatus = (int32_t *)(b + off); off += align_up((n_vectors + 1) * 4, 256);
     w.scan = (uint64_t *)(b + off); off += align_up(scan_scratch_words(n_vectors) * 8, 256);
     w.tag = w.scan + 8;
-    w.work = (uint32_t *)(b + off); off += (size_t)WORK_COUNTERS * WORK_STRIDE * 4;
+    w.work = (uint32_t *)(b + off); off += (size_t)(WORK_COUNTERS + 1) * WORK_STRIDE * 4;
     w.total = off;
     return w;
 }

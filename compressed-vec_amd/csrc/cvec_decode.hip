@@ -14,10 +14,13 @@
 //               its two elements of every octet straight out of the bitstream, keeps the XOR state
 //               in registers and either compares (filter) or stores.  No barriers, no octet table.
 //   k_finalize  one lane per vector folds its sections' results in order, so a failing section
-//               ends that vector exactly where the reference's iteration would stop.
+//               ends that vector exactly where the reference's iteration would stop; a pass that
+//               wants the total alone and met no failure takes the section kernel's sums instead.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
                                                uint64_t padded_bytes, const uint8_t *__restrict__ gate,
                                                uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
                                                uint64_t *__restrict__ result, uint64_t *__restrict__ tag,
-                                               uint64_t cookie, uint32_t *__restrict__ work) {
+                                               uint64_t cookie, uint32_t *__restrict__ work, uint32_t epoch) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     // One 4-byte load per section header (type byte + 16-bit length), pulled back inside the padded
     // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     // Whose index this workspace holds from now on (a gated index is nobody's): a later pass that reuses
     // the descriptors instead of walking the headers again checks it.
     if (v == 0) { tag[0] = gate ? 0ull : cookie; tag[1] = 0; }
-    if (v < WORK_COUNTERS) work[v * WORK_STRIDE] = 0; // the section kernel's range counters
+    // the section kernel's range counters and, on the same lines, its partial totals
+    if (v < WORK_COUNTERS) { work[v * WORK_STRIDE] = 0; work[v * WORK_STRIDE + 2] = 0; work[v * WORK_STRIDE + 3] = 0; }
     if (v >= n) return;
     const uint64_t start = byte_off[v], L = byte_off[v + 1] - start;
     const uint64_t slot0 = sec_base[v], nslots = sec_base[v + 1] - slot0;
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
     const uint64_t fill_off = start + (pos < L ? pos : L);
     for (; k < nslots; k++) desc[slot0 + k] = desc_pack(fill_off, 0, K_SKIP);
     vstatus[v] = st;
+    if (st != CVEC_OK) work[FAIL_FLAG_WORD] = epoch; // a vector of this pass failed: the finalize pass has to fold per vector
 }
 
 } // namespace cvec
@@ -273,17 +278,13 @@ struct ChunkPlan {
 // probe build: per-wave wall-clock stamps (100 MHz) of k_sections (start, end), read back by cvec_debug_sections_times
 __device__ uint64_t g_sec_stamps[8192 * 2];
 hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_sec_stamps), sizeof(g_sec_stamps)); }
-#ifdef CVEC_NO_STAMPS
-#define SEC_STAMP(i) do { } while (0)
-#else
 #define SEC_STAMP(i) do { const uint32_t gw_ = blockIdx.x * SEC_WAVES + wave; if (lane == 0 && gw_ < 8192) g_sec_stamps[gw_ * 2 + (i)] = wall_clock64(); } while (0)
-#endif
 #else
 #define SEC_STAMP(i) do { } while (0)
 #endif
 
 // k_sections: every wave is on its own.  A wave works through ranges of section slots (its first one fixed,
-// the others drawn from the workspace's counters) with an 18 or 12 KiB staging region in LDS, and loops
+// the others drawn from the workspace's counters) with an 18, 12 or 6 KiB staging region in LDS, and loops
 // over chunks of up to 16 sections.  Per chunk: the bytes
 // prefetched into registers during the previous chunk's compute are written to the region; the next
 // chunk is planned from its descriptors and its global loads are issued into those registers (plus
@@ -292,14 +293,14 @@ hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_
 // stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
 // No barriers; the only traffic between waves are the range counters.
 template <int ETYPE, int MODE, int NPRED, int PIECES>
-__global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2) void k_sections(const uint8_t *__restrict__ bytes,
+__global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec_wg_per_cu(PIECES), sec_wg_per_cu(PIECES)))) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
                                                           uint32_t *__restrict__ sec_res,
                                                           uint8_t *__restrict__ masks, void *__restrict__ out_,
                                                           const uint64_t *__restrict__ tag, uint64_t cookie,
                                                           const uint8_t *__restrict__ gate, uint32_t *__restrict__ work,
-                                                          uint32_t n_groups, uint32_t keep_cached) {
+                                                          uint32_t n_groups, uint32_t epoch, uint32_t keep_cached) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared<PIECES> sm;
     // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
@@ -429,6 +430,10 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
     // while a store is in flight has to drain the store too (a write round trip per chunk otherwise).
     uint32_t res_word = 0, mk_lo = 0, mk_hi = 0; // mask dwords q and 4 + q of the lane's section
     uint64_t res_slot = 0;
+    // What the wave's sections counted, and whether one of them failed: while no section and no vector header of
+    // a pass fails, the pass's total is the sum of these, and the finalize pass need not fold per vector.
+    uint64_t acc_cnt = 0;
+    uint32_t acc_bad = 0;
     bool res_pending = false, mk_pending = false;
     // A use of the first descriptor ahead of the loop: entering the loop with that load in flight would
     // put a full wait in front of the plan in every pass, right behind the deferred store.
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
             for (int i = 0; i < PIECES; i++) dst[64 * i + lane] = R[i];
         }
         __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
-        if (res_pending) sec_res[res_slot] = res_word;
+        if (res_pending) { sec_res[res_slot] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
         res_pending = false;
         if constexpr (MODE == MODE_FILTER_MASKS) {
             if (mk_pending) {
@@ -569,11 +574,20 @@ __global__ __launch_bounds__(SEC_THREADS, PIECES <= REGION_PIECES_SMALL ? 3 : 2)
         cur = nxt;
         s_next = s_after;
     }
-    if (res_pending) sec_res[res_slot] = res_word;
+    if (res_pending) { sec_res[res_slot] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
     if constexpr (MODE == MODE_FILTER_MASKS) {
         if (mk_pending) {
             uint32_t *m = (uint32_t *)(masks + res_slot * 32) + (lane & 3);
             m[0] = mk_lo; m[4] = mk_hi;
+        }
+    }
+    if (work != nullptr) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc_cnt += __shfl_down(acc_cnt, d, 64);
+        const bool bad = __ballot((acc_bad >> 16) != 0) != 0;
+        if (lane == 0) {
+            if (acc_cnt) atomicAdd((unsigned long long *)(work + (size_t)(blockIdx.x % n_groups) * WORK_STRIDE + 2), (unsigned long long)acc_cnt);
+            if (bad) work[FAIL_FLAG_WORD] = epoch;
         }
     }
     SEC_STAMP(1);
@@ -587,13 +601,21 @@ __global__ __launch_bounds__(256) void k_finalize(const uint64_t *__restrict__ s
                                                   const int32_t *__restrict__ vstatus,
                                                   uint64_t *__restrict__ per_vec, int32_t *__restrict__ status_out,
                                                   uint64_t *__restrict__ result, const uint64_t *__restrict__ tag,
-                                                  uint64_t cookie) {
+                                                  uint64_t cookie, const uint32_t *__restrict__ work, uint32_t epoch) {
     __shared__ uint64_t s_cnt[4];
     __shared__ uint32_t s_nerr[4], s_max[4];
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t cnt = 0;
     uint32_t st = 0;
     const bool stale = tag != nullptr && *tag != cookie; // the section pass did not run: see k_sections
+    // Nobody asks for per-vector results and nothing failed in this pass (no vector header, no section: the flag
+    // word would carry the pass's number): the total is the sum of what the section kernel's waves counted, and
+    // the number of failed vectors and the largest status stay zero.
+    if (work != nullptr && per_vec == nullptr && status_out == nullptr && !stale && work[FAIL_FLAG_WORD] != epoch) {
+        if (blockIdx.x != 0) return;
+        for (uint32_t g = threadIdx.x; g < (uint32_t)WORK_COUNTERS; g += blockDim.x) cnt += *(const uint64_t *)(work + (size_t)g * WORK_STRIDE + 2);
+        v = n; // no vector of its own: straight to the block's reduction
+    }
     if (v < n) {
         const uint64_t a = sec_base[v], b = stale ? a : sec_base[v + 1];
         const uint32_t hst = (uint32_t)vstatus[v];
@@ -726,7 +748,8 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
 template <int ETYPE>
 static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
                             const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, const uint64_t *tag,
-                            uint64_t cookie, const uint8_t *d_gate, uint64_t n_bytes, uint32_t *work, hipStream_t stream) {
+                            uint64_t cookie, const uint8_t *d_gate, uint64_t n_bytes, uint32_t *work, uint32_t epoch,
+                            hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
         // range of section slots (a multiple of TILE).  Count-only passes over a batch whose average
@@ -744,9 +767,17 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
 #endif
         const bool count_only = mode != MODE_DECODE && d_masks == nullptr;
         bool small = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL);
-        if (shape_env == 1) small = false;
-        if (shape_env == 2) small = count_only;
-        const int wgcu = wgcu_env > 0 ? wgcu_env : (small ? 3 : 2);
+        // A third shape, 6 KiB regions at four workgroups per CU, for count-only passes over batches whose sections
+        // average at most 378 bytes (dense integers, deltas): dense u32 0.202 -> 0.190 ms per GiB, u64 delta 0.171 ->
+        // 0.169.  (Decode passes were measured on it too and lose 3 to 6 %: more waves interleave more partial-line
+        // stores; they keep the 18 KiB shape.)
+        bool tiny = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_TINY);
+        if (shape_env == 1) small = tiny = false;
+        if (shape_env == 2) { small = count_only; tiny = false; }
+        if (shape_env == 3) tiny = count_only;
+        if (shape_env == 4) tiny = false;
+        if (tiny) small = false;
+        const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
         uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
 #ifdef CVEC_PROBES
         // probe build: a cap on the waves of a launch, so that small test batches run with many ranges per wave
@@ -793,11 +824,13 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
 #define CVEC_LAUNCH_SEC_P(M, N, P)                                                                                  \
     k_sections<ETYPE, M, N, P><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
-                                                                tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, keep_cached)
+                                                                tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
-        /* (the conditional constant keeps the shape a mode never takes from being instantiated) */                \
-        if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small)                                                   \
+        /* (the conditional constants keep the shapes a mode never takes from being instantiated) */                \
+        if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && tiny)                                                    \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_TINY : REGION_PIECES)); \
+        else if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small)                                              \
             CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_SMALL : REGION_PIECES)); \
         else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES);                                                                \
     } while (0)
@@ -840,7 +873,7 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     SinkArgs sa;
     memset(&pa, 0, sizeof(pa));
     memset(&sa, 0, sizeof(sa));
-    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, nullptr, stream);
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, nullptr, 0, stream);
     return hipGetLastError();
 }
 
@@ -873,6 +906,16 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
         cookie = (cookie ^ x) * 0xff51afd7ed558ccdull, cookie ^= cookie >> 29;
     cookie |= 1;
     const uint64_t *check = phase == READ_INDEXED ? tag : nullptr;
+    // The number of this pass: kernels that meet a failed vector or section write it into the workspace's flag word,
+    // and the finalize pass takes the short way (total = the section kernel's sums) only if the word holds another
+    // value.  Stale or uninitialised contents can only send it the long way.  Not with a gate (closed chunks are
+    // written off outside the accumulating store, and an indexed gated pass has fixed ranges), not under the
+    // reference's tail rule (its fix-up pass changes per-section counts after the section kernel), and not without
+    // sections (no section kernel runs), and not over a resident index (the vector headers were checked by an
+    // earlier pass).
+    static std::atomic<uint32_t> g_epoch{1};
+    const uint32_t epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
+    const bool fast_total = phase == READ_ALL && d_gate == nullptr && g_tail_rule == 0 && ns > 0 && n > 0;
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
     // (the reference's tail rule is applied by a pass over the section descriptors: the section-slot path)
     if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS && g_tail_rule == 0) {
@@ -896,14 +939,14 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     if (phase != READ_INDEXED)
         k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
                                                                                      n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
-                                                                                     vstatus, d_result, tag, cookie, work);
+                                                                                     vstatus, d_result, tag, cookie, work, epoch);
     else
         k_begin_indexed<<<1, 256, 0, stream>>>(d_result, work); // k_index does this otherwise
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)
         launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
-                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, work, stream);
+                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, work, epoch, stream);
     timer_mark(rec, 3, stream);
     if (g_tail_rule != 0 && phase != READ_INDEX_ONLY)
         (void)launch_ref_tail_fix(ETYPE, mode == MODE_DECODE ? 1 : 0, b, desc, sec_res, pa, sa, d_masks, d_out, check, cookie,
@@ -911,7 +954,8 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,
-                                                                    d_status, d_result, check, cookie);
+                                                                    d_status, d_result, check, cookie, fast_total ? work : nullptr,
+                                                                    epoch);
     timer_mark(rec, 5, stream);
 }
 

@@ -29,7 +29,9 @@ enum { PATH_AUTO = 0, PATH_SLOTS = 1, PATH_VSTREAM = 2 }; // which read kernel s
 // Range counters of the section kernel in a read workspace: WORK_COUNTERS counters, each on a 128-byte line of its own.
 constexpr int WORK_COUNTERS = 256;
 constexpr int WORK_STRIDE = 32; // in 32-bit words
-
+// Words 2..3 of a counter's line: a 64-bit partial total of the section kernel.  One more line behind the counters
+// holds the number of the last pass in which a vector or a section failed.
+constexpr int FAIL_FLAG_WORD = WORK_COUNTERS * WORK_STRIDE;
 
 // Second tag word of a read workspace: set when its per-vector array holds the valid-section counts of a
 // vector-streaming pass (k_vstream) instead of the header statuses of an index pass (k_index).

@@ -22,6 +22,11 @@ constexpr int TILE = 16; // sections per chunk: one per quad of lanes
 // 0.159 ms per GiB); 16 incompressible f32 sections do not fit 12 KiB and lose more lanes than that gains.
 constexpr int REGION_PIECES = 18;
 constexpr int REGION_PIECES_SMALL = 12;
+constexpr int REGION_PIECES_TINY = 6; // 6 KiB regions at four workgroups per CU: sections of a few hundred bytes
+// Workgroups of the section kernel that share a CU (= its waves per SIMD: a workgroup is one wave per SIMD), per
+// region shape.  The kernel carries it as an explicit occupancy bound, which makes the compiler size the register
+// allocation so that the hardware cannot place more; the build checks the kernel descriptors against it (Makefile).
+constexpr int sec_wg_per_cu(int pieces) { return pieces <= REGION_PIECES_TINY ? 4 : (pieces <= REGION_PIECES_SMALL ? 3 : 2); }
 
 // The last 64 bytes of a region stay zero: sections without octets (Null, Const, skipped slots) run
 // the octet loop over them (32 empty octets), which keeps the loop free of per-kind masking.

@@ -77,11 +77,14 @@ template <int SP> struct VsShared {
 
 constexpr uint32_t VS_K_NEW = 0xffffffffu; // value of the section counter while the vector's header is unchecked
 
-template <int ETYPE, int MODE, int NPRED, int SP>
+// workgroups of the kernel per CU, by window size (stated on the kernel; the build checks the kernel descriptors
+// against it, see the Makefile)
 #ifndef VS_MINBLOCKS
-#define VS_MINBLOCKS (SP <= 48 ? 3 : 2)
+#define VS_MINBLOCKS(sp) ((sp) <= 48 ? 3 : 2)
 #endif
-__global__ __launch_bounds__(SEC_THREADS, VS_MINBLOCKS) void k_vstream(
+constexpr int vs_wg_per_cu(int sp) { return VS_MINBLOCKS(sp); }
+template <int ETYPE, int MODE, int NPRED, int SP>
+__global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_wg_per_cu(SP), vs_wg_per_cu(SP)))) void k_vstream(
     const uint8_t *__restrict__ bytes, uint32_t padded_bytes, const uint64_t *__restrict__ byte_off,
     const uint64_t *__restrict__ sec_base, uint32_t n, uint32_t per, PredArgs pa, SinkArgs sa,
     uint64_t *__restrict__ per_vec, int32_t *__restrict__ status_out, uint8_t *__restrict__ masks, void *__restrict__ out_,

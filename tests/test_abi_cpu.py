@@ -103,3 +103,22 @@ def test_synth_generator_matches_bench_shape():
     assert 0.5 < (s != 0).mean() < 0.7                          # ~60 % density
     vals, eo = synth.batch_values("u64_delta", 3, 100)
     assert vals.dtype == np.uint64 and vals.min() > 100000 and list(eo) == [0, 100, 200, 300]
+
+
+def test_shipped_library_has_no_shift_count_in_the_last_vgpr_and_the_meant_occupancy():
+    """gfx950 can read VGPR0 instead of the last VGPR of a wave's allocation when a 64-bit shift takes its count
+    from it (tools/mb/topvgpr.hip); the build passes the library through tools/check_vgpr_hazard.py, and the file
+    that ships must come out clean, with the read kernels at the workgroups per CU their LDS regions are cut for."""
+    import subprocess
+    import sys
+    import compressed_vec_amd as cv
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_vgpr_hazard.py"),
+                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi6EE=4",
+                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi12EE=3",
+                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi18EE=2",
+                        "--expect", "k_vstreamILi[0-9]+ELi[0-9]+ELi[0-9]+ELi72EE=2", cv.LIB_PATH],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "kernels" in r.stdout

@@ -461,9 +461,11 @@ def test_malformed_vectors_report_status_and_partial_counts(cv, oracle):
 
 
 def test_total_only_pass_equals_the_per_vector_pass(cv, oracle):
-    """A pass that asks for nothing but the result block must give the result block of a pass with per-vector
-    outputs: on a clean batch, on batches with a damaged header, a damaged section, a section of an illegal
-    kind - and again on the clean batch afterwards."""
+    """A pass that asks for nothing but the result block takes the section kernel's own sums as the total when no
+    vector header and no section failed, and folds per vector otherwise.  Both ways must give the result block of
+    a pass with per-vector outputs: on a clean batch, on batches with a damaged header, a damaged section, a
+    section of an illegal kind - and again on the clean batch afterwards (the failure mark of an earlier pass
+    must not stick to the workspace)."""
     rng = np.random.default_rng(5)
     good = [oracle.encode_all(oracle.U32, rng.integers(0, 9, size=int(rng.integers(1, 3000))).astype(np.uint32))
             for _ in range(40)]
@@ -1097,10 +1099,10 @@ def test_reference_bench_configurations_vs_oracle(cv, oracle, name):
 
 @pytest.mark.parametrize("top,lo,hi", [(200, 0, 378), (1 << 15, 379, 700)])
 def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle, top, lo, hi):
-    """Count-only passes pick 12 KiB staging regions (three workgroups per CU) when 16 average sections fit
-    them, 18 KiB ones otherwise; a batch of small sections (two sizes) with a few vectors of incompressible
-    ones mixed in runs the small shape with chunks that break early, and must count like the oracle either
-    way."""
+    """Count-only passes pick 6 KiB staging regions (four workgroups per CU) or 12 KiB ones (three) when 16
+    average sections fit them, 18 KiB ones otherwise; a batch of small sections with a few vectors of
+    incompressible ones mixed in runs a small shape with chunks that break early, and must count like the
+    oracle either way."""
     rng = np.random.default_rng(77)
     small = [rng.integers(1, top, size=int(rng.integers(200, 3000))).astype(np.uint32) for _ in range(300)]
     big = [rng.integers(0, 1 << 32, size=2048, dtype=np.uint64).astype(np.uint32) for _ in range(6)]
@@ -1109,7 +1111,7 @@ def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle, top
     vals = np.concatenate(vecs)
     blob, bo = oracle.batch_encode(oracle.U32, vals, eo)
     dev = cv.EncodedBatch("u32", blob, bo).to_device()
-    assert lo <= dev.n_bytes // dev.n_sections <= hi           # the launcher's rule picks the 12 KiB shape
+    assert lo <= dev.n_bytes // dev.n_sections <= hi           # the launcher's rule picks the 6 KiB / the 12 KiB shape
     for p in (7, [7, 9, 150], int(big[0][5])):
         total, per = dev.filter_count(p, per_vector=True)
         wtotal, wper, _, rc = oracle.batch_filter_count(oracle.U32, blob, bo, p)
