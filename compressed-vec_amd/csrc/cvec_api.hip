@@ -471,6 +471,7 @@ static ReadWs carve_read_ws(void *base, uint64_t n_vectors, uint64_t n_sections)
     w.scan = (uint64_t *)(b + off); off += align_up(scan_scratch_words(n_vectors) * 8, 256);
     w.tag = w.scan + 8;
     w.work = (uint32_t *)(b + off); off += (size_t)(WORK_COUNTERS + 1) * WORK_STRIDE * 4;
+    off += align_up(n_sections + 1, 256); // behind the counters: one byte per section, its distance to the vector's end
     w.total = off;
     return w;
 }

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
                                                uint64_t padded_bytes, const uint8_t *__restrict__ gate,
                                                uint64_t *__restrict__ desc, int32_t *__restrict__ vstatus,
                                                uint64_t *__restrict__ result, uint64_t *__restrict__ tag,
-                                               uint64_t cookie, uint32_t *__restrict__ work, uint32_t epoch) {
+                                               uint64_t cookie, uint32_t *__restrict__ work, uint32_t epoch,
+                                               uint8_t *__restrict__ tail) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     // One 4-byte load per section header (type byte + 16-bit length), pulled back inside the padded
     // allocation at the very end of the blob: the chain of dependent loads is what this kernel costs.
@@ -185,10 +186,12 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
         bool walking = true;
         while (walking && pos < L) {
             uint64_t found[8];
+            uint8_t ftail[8]; // bytes between the section's end and the vector's end (255: that many or more)
             int nfound = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 found[j] = 0;
+                ftail[j] = 255;
                 if (walking && pos < L) {
                     const uint64_t rem = L - pos;
                     const uint32_t hw = load4(start + pos);
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
                         }
                         found[j] = off ? desc_pack(start + pos, 0, K_GATED)
                                        : desc_pack(start + pos, (uint32_t)nb, legal ? b0 : K_ILLEGAL);
+                        ftail[j] = (uint8_t)(rem - nb < 255 ? rem - nb : 255);
                         nfound = j + 1;
                         pos += nb;
                         k++;
@@ -237,12 +241,12 @@ __global__ __launch_bounds__(256) void k_index(const uint8_t *__restrict__ bytes
             }
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (j < nfound) desc[slot0 + k - nfound + j] = found[j];
+                if (j < nfound) { desc[slot0 + k - nfound + j] = found[j]; tail[slot0 + k - nfound + j] = ftail[j]; }
         }
         if (st == CVEC_OK && k != nslots) st = CVEC_ERR_SECTION_COUNT;
     }
     const uint64_t fill_off = start + (pos < L ? pos : L);
-    for (; k < nslots; k++) desc[slot0 + k] = desc_pack(fill_off, 0, K_SKIP);
+    for (; k < nslots; k++) { desc[slot0 + k] = desc_pack(fill_off, 0, K_SKIP); tail[slot0 + k] = 255; }
     vstatus[v] = st;
     if (st != CVEC_OK) work[FAIL_FLAG_WORD] = epoch; // a vector of this pass failed: the finalize pass has to fold per vector
 }
@@ -272,6 +276,7 @@ struct ChunkPlan {
     uint32_t rel;  // the lane's section: start inside the region,
     uint32_t len;  //   clipped length,
     uint32_t kind; //   kind (K_SKIP beyond the chunk)
+    int32_t tail_from; // reference tail rule only: region offset from which an octet starts within 33 bytes of the vector's end
 };
 
 #ifdef CVEC_PROBES
@@ -292,7 +297,9 @@ hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_
 // (process_chunk) while the loads fly.  Registers, not a second LDS region, double-buffer the
 // stream: LDS capacity bounds the resident waves (8 per CU), the register file has room to spare.
 // No barriers; the only traffic between waves are the range counters.
-template <int ETYPE, int MODE, int NPRED, int PIECES>
+// TAILREF: the reference crate's tail decoder instead of the format's rule for the last octets of a vector (see
+// process_chunk); `tail` = the index pass's per-section distances to the vector's end.
+template <int ETYPE, int MODE, int NPRED, int PIECES, int TAILREF = 0>
 __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec_wg_per_cu(PIECES), sec_wg_per_cu(PIECES)))) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
@@ -300,7 +307,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
                                                           uint8_t *__restrict__ masks, void *__restrict__ out_,
                                                           const uint64_t *__restrict__ tag, uint64_t cookie,
                                                           const uint8_t *__restrict__ gate, uint32_t *__restrict__ work,
-                                                          uint32_t n_groups, uint32_t epoch, uint32_t keep_cached) {
+                                                          uint32_t n_groups, uint32_t epoch, uint32_t keep_cached,
+                                                          const uint8_t *__restrict__ tail) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     __shared__ SecShared<PIECES> sm;
     // Descriptors reused from an earlier pass: they are only followed if the workspace says that they are
@@ -375,6 +383,12 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         c.nch = (e + 15) >> 4;
         c.rel = (uint32_t)(off - c.gb);
         c.kind = sec < c.n ? desc_kind(d) : K_SKIP;
+        c.tail_from = 0x7fffffff;
+        if constexpr (TAILREF != 0) {
+            // (a load per chunk, issued with the chunk's staging loads and used one loop pass later)
+            const uint32_t td = sec < c.n ? tail[s + sec] : 255u;
+            if (td < 34u) c.tail_from = (int32_t)(c.rel + c.len + td) - 33;
+        }
         return c;
     };
 
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     // The first pass of the loop has an empty current chunk: it only plans and loads chunk 0.
     uint64_t s_cur = sA, s_next = sA;
     ChunkPlan cur;
-    cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP;
+    cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP; cur.tail_from = 0x7fffffff;
     // the wave's next range is asked for one range ahead: the counter's answer has a whole range to arrive
     uint32_t ticket = 0;
     // the counter this wave draws from: one of its XCD's (n_groups / 8 per XCD, so that a counter's line stays in one
@@ -556,13 +570,15 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
 #else
             const out_rsrc_t orsrc = chunk_out_rsrc<W, MODE>(out_, s_cur + sec, lane, ooff);
 #endif
-            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES)>(
-                data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff);
+            // (region offset -> LDS address; sections that end far from the vector's end keep "never")
+            const int32_t tail_from = TAILREF != 0 && cur.tail_from != 0x7fffffff ? (int32_t)lds_base + cur.tail_from : 0x7fffffff;
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF>(
+                data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from);
             if constexpr (W == 4) {
                 const unsigned long long odd_m = __ballot(odd); // a lane only sees the octets that store its own elements
                 if (odd_m != 0) {
-                    if ((odd_m >> ((uint32_t)lane & ~3u)) & 0xfull) section_exact<ETYPE, MODE, NPRED>(data, lds_base, cur.kind, cur.rel, cur.len, lane, pa, sa, res_word,
-                                                               mk_lo, mk_hi, orsrc, ooff);
+                    if ((odd_m >> ((uint32_t)lane & ~3u)) & 0xfull) section_exact<ETYPE, MODE, NPRED, TAILREF>(data, lds_base, cur.kind, cur.rel, cur.len, lane, pa, sa, res_word,
+                                                               mk_lo, mk_hi, orsrc, ooff, tail_from);
                 }
             }
             res_slot = s_cur + sec;
@@ -749,6 +765,7 @@ template <int ETYPE>
 static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *desc, uint64_t ns, const PredArgs &pa,
                             const SinkArgs &sa, uint32_t *sec_res, uint8_t *d_masks, void *d_out, const uint64_t *tag,
                             uint64_t cookie, const uint8_t *d_gate, uint64_t n_bytes, uint32_t *work, uint32_t epoch,
+                            const uint8_t *tail /* the index pass's tail distances: the reference's tail rule; or null */,
                             hipStream_t stream) {
     if (ns > 0) {
         // Persistent waves: 2 workgroups x 4 waves per CU (LDS-bound), each wave owning a contiguous
@@ -777,6 +794,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 3) tiny = count_only;
         if (shape_env == 4) tiny = false;
         if (tiny) small = false;
+        if (tail != nullptr) small = tiny = false; // the reference's tail rule is compiled for the large shape only
         const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
         uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
 #ifdef CVEC_PROBES
@@ -822,17 +840,18 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         uint32_t bucket = 1;
         while (bucket < pb.count) bucket *= 2;
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
-#define CVEC_LAUNCH_SEC_P(M, N, P)                                                                                  \
-    k_sections<ETYPE, M, N, P><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
-                                                                tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached)
+#define CVEC_LAUNCH_SEC_P(M, N, P, T)                                                                               \
+    k_sections<ETYPE, M, N, P, T><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
+                                                                   tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached, tail)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
         /* (the conditional constants keep the shapes a mode never takes from being instantiated) */                \
-        if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && tiny)                                                    \
-            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_TINY : REGION_PIECES)); \
+        if (tail != nullptr) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, 1); /* the reference's tail rule: the large shape only */ \
+        else if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && tiny)                                               \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_TINY : REGION_PIECES), 0); \
         else if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small)                                              \
-            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_SMALL : REGION_PIECES)); \
-        else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES);                                                                \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_SMALL : REGION_PIECES), 0); \
+        else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, 0);                                                             \
     } while (0)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \
     switch (bucket) {                                                                                               \
@@ -873,7 +892,7 @@ hipError_t launch_raw_blocks_u64(const uint8_t *d_bytes, const uint64_t *desc, u
     SinkArgs sa;
     memset(&pa, 0, sizeof(pa));
     memset(&sa, 0, sizeof(sa));
-    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+    launch_sections<CVEC_U64>(MODE_DECODE, d_bytes, desc, n_blocks, pa, sa, sec_res, nullptr, d_out, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, stream);
     return hipGetLastError();
 }
 
@@ -887,10 +906,6 @@ hipError_t launch_vstream(int mode, const cvec_dbatch_view &b, const PredArgs &p
                           uint64_t *tag, hipStream_t stream);
 static int g_read_path = PATH_AUTO;
 void set_read_path(int path) { g_read_path = path; }
-// cvec_tailfix.hip
-hipError_t launch_ref_tail_fix(int etype, int decode, const cvec_dbatch_view &b, const uint64_t *desc, uint32_t *sec_res,
-                               const PredArgs &pa, const SinkArgs &sa, uint8_t *d_masks, void *d_out, const uint64_t *tag,
-                               uint64_t cookie, hipStream_t stream);
 static int g_tail_rule = 0; // 0: the format's bitstream rule; 1: the reference crate's tail decoder
 void set_tail_rule(int rule) { g_tail_rule = rule; }
 
@@ -909,15 +924,17 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     // The number of this pass: kernels that meet a failed vector or section write it into the workspace's flag word,
     // and the finalize pass takes the short way (total = the section kernel's sums) only if the word holds another
     // value.  Stale or uninitialised contents can only send it the long way.  Not with a gate (closed chunks are
-    // written off outside the accumulating store, and an indexed gated pass has fixed ranges), not under the
-    // reference's tail rule (its fix-up pass changes per-section counts after the section kernel), and not without
+    // written off outside the accumulating store, and an indexed gated pass has fixed ranges), not without
     // sections (no section kernel runs), and not over a resident index (the vector headers were checked by an
     // earlier pass).
     static std::atomic<uint32_t> g_epoch{1};
     const uint32_t epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
-    const bool fast_total = phase == READ_ALL && d_gate == nullptr && g_tail_rule == 0 && ns > 0 && n > 0;
+    const bool fast_total = phase == READ_ALL && d_gate == nullptr && ns > 0 && n > 0;
+    // per-section distance to the vector's end, behind the range counters: written by every index pass, read by the
+    // section kernel under the reference's tail rule
+    uint8_t *const tail = (uint8_t *)(work + (size_t)(WORK_COUNTERS + 1) * WORK_STRIDE);
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
-    // (the reference's tail rule is applied by a pass over the section descriptors: the section-slot path)
+    // (the reference's tail rule needs the index pass's distances: the section-slot path)
     if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS && g_tail_rule == 0) {
         // sparse batches of many vectors: one kernel, no section index, no per-section results (the timing slots of
         // the index and finalize kernels hold the memset and nothing)
@@ -939,18 +956,16 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     if (phase != READ_INDEXED)
         k_index<ETYPE><<<(uint32_t)((n > 0 ? n + 255 : 256) / 256), 256, 0, stream>>>(b.d_bytes, b.d_byte_off, b.d_sec_base,
                                                                                      n, (b.n_bytes + 15) & ~15ull, d_gate, desc,
-                                                                                     vstatus, d_result, tag, cookie, work, epoch);
+                                                                                     vstatus, d_result, tag, cookie, work, epoch, tail);
     else
         k_begin_indexed<<<1, 256, 0, stream>>>(d_result, work); // k_index does this otherwise
     timer_mark(rec, 1, stream);
     timer_mark(rec, 2, stream);
     if (phase != READ_INDEX_ONLY)
         launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
-                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, work, epoch, stream);
+                               phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, work, epoch,
+                               g_tail_rule != 0 ? tail : nullptr, stream);
     timer_mark(rec, 3, stream);
-    if (g_tail_rule != 0 && phase != READ_INDEX_ONLY)
-        (void)launch_ref_tail_fix(ETYPE, mode == MODE_DECODE ? 1 : 0, b, desc, sec_res, pa, sa, d_masks, d_out, check, cookie,
-                                  stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)
         k_finalize<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(b.d_sec_base, n, sec_res, vstatus, d_per_vector,

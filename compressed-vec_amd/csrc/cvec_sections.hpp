@@ -140,11 +140,21 @@ __device__ __forceinline__ out_rsrc_t chunk_out_rsrc(void *out_, uint64_t slot, 
 // ZPAD = offset in the region of 64 zero bytes: sections without octets run the loop over them.
 // MODE_DECODE output goes through the buffer descriptor `orsrc`; `ooff` is the lane's byte offset in it
 // for elements 2q and 2q+1 of octet 0 of its section (out of range for lanes that must store nothing).
-template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD>
+//
+// TAILREF: the reference crate's tail decoder (cvec_set_tail_rule).  unpack8_u32_simd leaves its SIMD preload when
+// fewer than 34 bytes of its input slice are left (src/nibblepack_simd.rs:546-554), and the fallback for octets of
+// 5 to 8 nibbles, preload_u32x8_nibbles (:433-450), returns zeros.  The slice a section's decoder is handed runs to
+// the end of the VECTOR (src/section.rs:706, src/vector.rs:443), and 64-bit octets whose bits fit 32 take the same
+// unpacker (src/nibblepacking.rs:431-434).  So the crate decodes such an octet to "no lane stored": here its mask
+// is cleared for the extraction (the walk still uses the real one), which also leaves an Xor section's state as
+// the crate's XorSink leaves it (src/sink.rs:271-275).  `tail_from` = the first LDS address from which an octet
+// start is within 33 bytes of the vector's end (beyond every address for sections that end further away).
+template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
-                                              uint32_t &mask_hi, out_rsrc_t orsrc, uint32_t ooff_in) {
+                                              uint32_t &mask_hi, out_rsrc_t orsrc, uint32_t ooff_in,
+                                              int32_t tail_from = 0x7fffffff) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
     const uint32_t q = lane & 3;
@@ -227,8 +237,16 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         }
         // ---- per-octet constants ---------------------------------------------------------------------------
         o.t4 = nw << 2; // trailing zero bits (a 32-bit shift uses bits 4:0 of its count; bits 5:4 only matter to section_exact and 64-bit)
-        o.sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
-        o.sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
+        uint32_t mask_x = mask; // the mask the extraction sees
+        if constexpr (TAILREF) {
+            // 5..8 nibbles ((nw >> 6) == 1; wider octets go to section_exact / fail) within 33 bytes of the vector's end;
+            // a 64-bit octet only if it takes the 32-bit unpacker (4n + tz <= 32)
+            bool drop = (int32_t)pa_cur >= tail_from && (nw >> 6) == 1u;
+            if constexpr (W == 8) drop = drop && n4 + ((nw & 15u) << 2) <= 32u;
+            mask_x = drop ? 0u : mask;
+        }
+        o.sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask_x, q2, 1u);     // all ones iff element 2q is stored
+        o.sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask_x, q2 + 1u, 1u);
         if constexpr (W == 4) racc |= nw & (o.sm0 | o.sm1); // the quad's lanes cover every stored element
         o.sh1 = n4 & o.sm0; // the second field lies n4 bits further on if the first one is stored
         if constexpr (W == 4) {
@@ -397,10 +415,11 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
 // (src/nibblepack_simd.rs:581).  A plain rolled loop over the 32 octets: such sections only come from damaged or
 // hand-made input, so its speed does not matter and its small register footprint does.  Same results
 // layout as process_chunk.  Call with all four lanes of the quad, for kinds NP / DELTA / XOR / RAW only.
-template <int ETYPE, int MODE, int NPRED>
+template <int ETYPE, int MODE, int NPRED, int TAILREF = 0>
 __device__ inline void section_exact(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel, uint32_t len,
                                      int lane, const PredArgs &pa, const SinkArgs &sa, uint32_t &sec_result,
-                                     uint32_t &mask_lo, uint32_t &mask_hi, out_rsrc_t orsrc, uint32_t ooff) {
+                                     uint32_t &mask_lo, uint32_t &mask_hi, out_rsrc_t orsrc, uint32_t ooff,
+                                     int32_t tail_from = 0x7fffffff) {
     static_assert(ETYPE != CVEC_U64, "64-bit sections have no inexact case");
     const uint32_t q = (uint32_t)lane & 3u;
     const uint32_t end = rel + len;
@@ -413,7 +432,10 @@ __device__ inline void section_exact(const uint8_t *data, uint32_t lds_base, uin
         const uint32_t m = data[p], nw = data[p + 1];
         const uint32_t n4 = 4u * ((nw >> 4) + 1u), pc = (uint32_t)__popc(m);
         if (m) hmax = max(hmax, nw >> 4);
-        const uint32_t fm = (nw & 8u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
+        uint32_t fm = (nw & 8u) ? 0u : 0xffffffffu >> ((32u - n4) & 31u);
+        if constexpr (TAILREF) {
+            if ((int32_t)(lds_base + p) >= tail_from && (nw >> 6) == 1u) fm = 0u; // the crate's tail decoder: see process_chunk
+        }
         uint32_t x[2];
 #pragma unroll
         for (uint32_t j = 0; j < 2; j++) {

@@ -138,8 +138,9 @@ cvec_status cvec_set_read_path(int32_t path);
  * falls back to preload_u32x8_nibbles (:433-450, :546-554), which yields zeros for the fields of octets of
  * 5 to 8 nibbles, so such octets decode as if all their fields were zero (an Xor section repeats its previous
  * values from there on).  Under this rule decode, counts, per-vector counts and masks of the _dev and _batch
- * read operations equal the crate's on well-formed vectors; passes take the section-slot kernels plus one
- * short pass per call.  The legacy stream codecs are not affected.  Process-wide. */
+ * read operations equal the crate's on well-formed vectors; passes take the section-slot kernels, which clear
+ * the masks of such octets as they decode (no extra pass, no measurable cost).  The legacy stream codecs are not
+ * affected.  Process-wide. */
 enum { CVEC_TAIL_FORMAT = 0, CVEC_TAIL_REFERENCE = 1 };
 cvec_status cvec_set_tail_rule(int32_t rule);
 

@@ -243,6 +243,35 @@ def test_reference_tail_rule_on_ragged_vectors(cv, oracle, reference_rule, tname
     assert not np.array_equal(np.asarray(dec_f).view(np.uint8), np.asarray(dec_r).view(np.uint8))
 
 
+def test_reference_tail_rule_behind_a_gate_over_a_resident_index(cv, oracle, reference_rule):
+    """MultiVectorFilter under the reference's tail rule, the later columns gated and read over resident section
+    indexes: a section that the gate closed yields an empty mask and no count whatever its last octets hold, an
+    open one decodes like the crate; per-row counts against the oracle's MultiVectorFilter in its reference mode
+    (every vector ends on a section boundary in wide octets, so the rule matters in every row)."""
+    rng = np.random.default_rng(91)
+    n, length = 160, 1024
+    def column(p_hit, value):
+        x = (rng.integers(1 << 20, 1 << 28, size=(n, length)) / 1.4).astype(np.float32)   # 7-8 nibble XOR octets
+        hit = rng.random((n, length // 256)) < p_hit
+        x[np.repeat(hit, 256, axis=1) & (rng.random((n, length)) < 0.4)] = value
+        return x
+    cols_np = [column(0.3, 3.0), column(0.7, 5.0), column(0.7, 3.0)]
+    eo = np.arange(n + 1, dtype=np.uint64) * length
+    preds = [3.0, 5.0, 3.0]
+    devs = [cv.encode_batch("f32", c.reshape(-1), eo).to_device() for c in cols_np]
+    for d in devs[1:]:
+        d.build_index()
+    total, per_row = cv.multi_filter(devs, preds, per_row=True)
+    host = [d.download() for d in devs]
+    want = np.array([oracle.multi_filter_count(F32, [h.vector(v) for h in host], preds) for v in range(n)], dtype=np.uint64)
+    assert np.array_equal(per_row, want) and total == int(want.sum())
+    # the rule matters here: the format's rule counts more (the crate zeroes matching elements of the last octets)
+    cv.set_tail_rule("format")
+    total_f = cv.multi_filter(devs, preds)
+    cv.set_tail_rule("reference")
+    assert total_f >= total
+
+
 def test_sparse_bench_vector_built_through_append_nulls(cv, oracle):
     """The reference's very sparse u32 vector exactly as benches/bench.rs:160-170 builds it:
     append_nulls(2475), 50 values, append_nulls(4950), the same 50 values, finish(10000).  The bytes

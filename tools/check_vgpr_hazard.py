@@ -33,6 +33,7 @@ import sys
 import tempfile
 
 EXPECT = []  # (compiled regex, workgroups per CU)
+MATCHED = set()  # patterns of EXPECT that named at least one kernel
 LLVM = os.environ.get("CVEC_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 SHIFT = re.compile(r"\b(v_lshlrev_b64|v_lshrrev_b64|v_ashrrev_i64)(?:_e64)?\s+v\[\d+:\d+\],\s*v(\d+)\b")
@@ -121,6 +122,7 @@ def check_code_object(blob, label):
         for rx, want in EXPECT:
             for k in alloc:
                 if rx.search(k):
+                    MATCHED.add(rx.pattern)
                     fit = min(8, 512 // alloc[k], (160 * 1024) // lds[k] if lds[k] else 8)
                     if fit != want:
                         findings.append("%s: %s: %d workgroups per CU fit (%d VGPRs, %d bytes of LDS) where %d are meant" % (
@@ -179,6 +181,9 @@ def main(argv):
             print("%s: no gfx950 code object found" % path)
             return 2
         print("%s: %d code objects, %d kernels, %d 64-bit shifts with a VGPR count checked" % (path, n_co, n_k, n_s))
+    for rx, _ in EXPECT:
+        if rx.pattern not in MATCHED:
+            bad.append("--expect %s names no kernel" % rx.pattern)
     for line in bad:
         print("HAZARD " + line)
     if bad:
