@@ -339,7 +339,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     // section whose gate mask is empty becomes a K_GATED descriptor, as k_index would have made it.
     // Only the general filter modes take a gate (the launcher sends gated passes there): the count-only
     // bit-pattern mode and decode keep the pointer out of their loops.
-    const uint8_t *const gate_ = (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) ? gate : nullptr;
+    const uint8_t *const gate_ = (MODE == MODE_FILTER || mode_has_masks(MODE)) ? gate : nullptr;
     auto load_desc = [&](uint64_t s) -> uint64_t {
         uint64_t d = s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
         if (gate_ != nullptr) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     // A chunk's per-section results are stored one loop pass later, behind the wait for the prefetched
     // bytes: loads and stores share one in-order counter only among their own kind, so a wait for loads
     // while a store is in flight has to drain the store too (a write round trip per chunk otherwise).
-    uint32_t res_word = 0, mk_lo = 0, mk_hi = 0; // mask dwords q and 4 + q of the lane's section
+    uint32_t res_word = 0, mk_lo = 0, mk_hi = 0; // mask bytes 8q .. 8q + 7 of the lane's section (q = lane & 3)
     uint64_t res_slot = 0;
     // What the wave's sections counted, and whether one of them failed: while no section and no vector header of
     // a pass fails, the pass's total is the sum of these, and the finalize pass need not fold per vector.
@@ -462,18 +462,16 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
         if (res_pending) { sec_res[res_slot] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
         res_pending = false;
-        if constexpr (MODE == MODE_FILTER_MASKS) {
-            if (mk_pending) {
-                uint32_t *m = (uint32_t *)(masks + res_slot * 32) + (lane & 3);
-                m[0] = mk_lo; m[4] = mk_hi;
-            }
+        if constexpr (mode_has_masks(MODE)) {
+            // one 8-byte store per lane: the quads of a chunk write 16 x 32 contiguous bytes
+            if (mk_pending) *(uint2 *)(masks + res_slot * 32 + 8 * (lane & 3)) = uint2{mk_lo, mk_hi};
             mk_pending = false;
         }
         // ---- plan the next chunk and start its loads ------------------------------------------------------------
         // (unconditional, so that the staging registers never become conditionally assigned: past the
         // wave's range the plan is empty and the loads fetch nothing)
         ChunkPlan nxt = plan(s_next, d_next);
-        if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
+        if constexpr (MODE == MODE_FILTER || mode_has_masks(MODE)) {
             // Behind a selective gate most chunks are closed as a whole: their results (count 0, empty
             // masks) are written here and the wave moves on, asking for the descriptors and gate masks
             // of the next four chunks at once instead of paying one round trip per chunk of 16.
@@ -483,10 +481,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
                 };
                 auto store_closed = [&](uint64_t s) {
                     if ((lane & 3) == 0) sec_res[s + sec] = res_pack(0, 0);
-                    if constexpr (MODE == MODE_FILTER_MASKS) {
-                        uint32_t *m = (uint32_t *)(masks + (s + sec) * 32) + (lane & 3);
-                        m[0] = 0; m[4] = 0;
-                    }
+                    if constexpr (mode_has_masks(MODE)) *(uint2 *)(masks + (s + sec) * 32 + 8 * (lane & 3)) = uint2{0u, 0u};
                 };
                 while (closed(s_next, d_next)) {
                     store_closed(s_next);
@@ -591,11 +586,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         s_next = s_after;
     }
     if (res_pending) { sec_res[res_slot] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
-    if constexpr (MODE == MODE_FILTER_MASKS) {
-        if (mk_pending) {
-            uint32_t *m = (uint32_t *)(masks + res_slot * 32) + (lane & 3);
-            m[0] = mk_lo; m[4] = mk_hi;
-        }
+    if constexpr (mode_has_masks(MODE)) {
+        if (mk_pending) *(uint2 *)(masks + res_slot * 32 + 8 * (lane & 3)) = uint2{mk_lo, mk_hi};
     }
     if (work != nullptr) {
 #pragma unroll
@@ -782,7 +774,12 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
 #else
         constexpr int rounds = 1, wgcu_env = 0, shape_env = 0, ablate = 0;
 #endif
-        const bool count_only = mode != MODE_DECODE && d_masks == nullptr;
+        // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN
+        const uint32_t fb = (uint32_t)pa.v[0];
+        const bool bits_ok = pa.count <= 1 && (ETYPE != CVEC_F32 || ((fb & 0x7fffffffu) != 0 && (fb & 0x7fffffffu) <= 0x7f800000u));
+        // the smaller region shapes: count-only passes, and mask passes of the bit-pattern compare (the general mask
+        // mode needs more registers than three workgroups per CU leave)
+        const bool count_only = mode != MODE_DECODE && (d_masks == nullptr || bits_ok);
         bool small = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL);
         // A third shape, 6 KiB regions at four workgroups per CU, for count-only passes over batches whose sections
         // average at most 378 bytes (dense integers, deltas): dense u32 0.202 -> 0.190 ms per GiB, u64 delta 0.171 ->
@@ -847,10 +844,10 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
     do {                                                                                                            \
         /* (the conditional constants keep the shapes a mode never takes from being instantiated) */                \
         if (tail != nullptr) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, 1); /* the reference's tail rule: the large shape only */ \
-        else if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && tiny)                                               \
-            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_TINY : REGION_PIECES), 0); \
-        else if ((M == MODE_FILTER || M == MODE_FILTER_BITS) && small)                                              \
-            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || M == MODE_FILTER_BITS) ? REGION_PIECES_SMALL : REGION_PIECES), 0); \
+        else if ((M == MODE_FILTER || mode_bit_compare(M)) && tiny)                                                 \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || mode_bit_compare(M)) ? REGION_PIECES_TINY : REGION_PIECES), 0); \
+        else if ((M == MODE_FILTER || mode_bit_compare(M)) && small)                                                \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || mode_bit_compare(M)) ? REGION_PIECES_SMALL : REGION_PIECES), 0); \
         else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, 0);                                                             \
     } while (0)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \
@@ -869,13 +866,13 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
             const bool nt_out = ETYPE != CVEC_U64 && n_bytes * 20 >= raw && n_bytes * 20 <= raw * 7;
             if (nt_out) CVEC_LAUNCH_SEC(MODE_DECODE, 2); else CVEC_LAUNCH_SEC(MODE_DECODE, 1);
         }
-        else if (d_masks) { CVEC_LAUNCH_BUCKET(MODE_FILTER_MASKS); }
         else if (bucket == 1) {
-            // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN
-            const uint32_t fb = (uint32_t)pa.v[0];
-            const bool bits_ok = ETYPE != CVEC_F32 || ((fb & 0x7fffffffu) != 0 && (fb & 0x7fffffffu) <= 0x7f800000u);
-            if (bits_ok && !d_gate) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, 1); else CVEC_LAUNCH_SEC(MODE_FILTER, 1);
-        } else {
+            if (d_masks) { if (bits_ok) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS_BITS, 1); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, 1); }
+            else if (bits_ok && !d_gate) CVEC_LAUNCH_SEC(MODE_FILTER_BITS, 1);
+            else CVEC_LAUNCH_SEC(MODE_FILTER, 1);
+        }
+        else if (d_masks) { CVEC_LAUNCH_BUCKET(MODE_FILTER_MASKS); }
+        else {
             CVEC_LAUNCH_BUCKET(MODE_FILTER);
         }
 #undef CVEC_LAUNCH_BUCKET

@@ -36,7 +36,10 @@ constexpr int SEC_THREADS = SEC_WAVES * 64;
 
 // MODE_FILTER_BITS: count only, one predicate value whose IEEE == is the same as equality of the bit
 // patterns (any integer; a float that is neither zero nor NaN): matching needs no compare instruction.
-enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2, MODE_FILTER_BITS = 3 };
+// MODE_FILTER_MASKS_BITS: the same test, with the per-section masks.
+enum { MODE_FILTER = 0, MODE_DECODE = 1, MODE_FILTER_MASKS = 2, MODE_FILTER_BITS = 3, MODE_FILTER_MASKS_BITS = 4 };
+constexpr bool mode_has_masks(int mode) { return mode == MODE_FILTER_MASKS || mode == MODE_FILTER_MASKS_BITS; }
+constexpr bool mode_bit_compare(int mode) { return mode == MODE_FILTER_BITS || mode == MODE_FILTER_MASKS_BITS; }
 
 template <int PIECES>
 struct SecShared {
@@ -94,6 +97,39 @@ __device__ __noinline__ uint32_t walk_status(const uint8_t *data, uint32_t p, ui
         p += size;
     }
     return 0;
+}
+
+// The 32-byte mask of a section (byte = octet, LSB = first element, src/filter.rs:46, :95-101) from what the four
+// lanes of its quad collected.  Lane s of the quad holds its two match bits of octet k at bits 2k, 2k + 1 of the
+// 64-bit word (a_hi : a_lo), one shift-or per element and octet inside the octet loop; here, once per section, the
+// quad transposes: lane r ends up with mask bytes 8r .. 8r + 7 (out_lo = bytes 8r .. 8r + 3), so that the quad stores
+// 32 contiguous bytes and a chunk of 16 sections 512.  Lane r takes from every lane s the sixteen bits of octets
+// 8r .. 8r + 7 (quad broadcasts), packs the four lanes' bytes side by side (byte s = the pairs of four octets from
+// lane s) and transposes that 4 x 4 matrix of bit pairs with two masked swaps.
+__device__ __forceinline__ void quad_mask_bytes(uint32_t a_lo, uint32_t a_hi, uint32_t q, uint32_t &out_lo, uint32_t &out_hi) {
+    uint32_t h[4];
+    const bool upper = (q & 2u) != 0;
+    const uint32_t sh = (q & 1u) << 4;
+#define CVEC_QUAD_BCAST(S, CTRL)                                                                                       \
+    {                                                                                                                  \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_lo, CTRL, 0xf, 0xf, false);                \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a_hi, CTRL, 0xf, 0xf, false);                \
+        h[S] = __builtin_amdgcn_ubfe(upper ? hi : lo, sh, 16u);                                                        \
+    }
+    CVEC_QUAD_BCAST(0, 0x00) CVEC_QUAD_BCAST(1, 0x55) CVEC_QUAD_BCAST(2, 0xaa) CVEC_QUAD_BCAST(3, 0xff)
+#undef CVEC_QUAD_BCAST
+    const uint32_t x = h[0] | (h[1] << 16), y = h[2] | (h[3] << 16);
+    uint32_t v[2] = {__builtin_amdgcn_perm(y, x, 0x06040200u), __builtin_amdgcn_perm(y, x, 0x07050301u)};
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        // element (lane s, octet j) sits at bit 8s + 2j and goes to bit 8j + 2s: swap bit 0 of s and j, then bit 1
+        uint32_t w = v[i];
+        w = (w & ~(0x00cc00ccu | (0x00cc00ccu << 6))) | ((w & 0x00cc00ccu) << 6) | ((w >> 6) & 0x00cc00ccu);
+        w = (w & ~(0x0000f0f0u | (0x0000f0f0u << 12))) | ((w & 0x0000f0f0u) << 12) | ((w >> 12) & 0x0000f0f0u);
+        v[i] = w;
+    }
+    out_lo = v[0];
+    out_hi = v[1];
 }
 
 typedef __amdgpu_buffer_rsrc_t out_rsrc_t;
@@ -172,11 +208,14 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     // MODE_FILTER_BITS: the predicate's bits are XORed into the state (f32) or moved to the other side of
     // the Delta add (integers), so that an element matches iff its word is zero
     U tgt = 0;
-    if constexpr (MODE == MODE_FILTER_BITS) {
+    if constexpr (mode_bit_compare(MODE)) {
         if constexpr (ETYPE == CVEC_F32) { st0 ^= (U)pa.v[0]; st1 = st0; }
         else tgt = (U)pa.v[0] - base;
     }
     uint32_t mism = 0;
+    // mask modes: the lane's two match bits (MODE_FILTER_MASKS) or mismatch bits (MODE_FILTER_MASKS_BITS) of octet k at
+    // bits 2k, 2k + 1 of (acc_hi : acc_lo); the quad turns them into mask bytes once, behind the loop
+    uint32_t acc_lo = 0, acc_hi = 0;
     mask_lo = 0; mask_hi = 0;
     const uint32_t lowmask = (1u << (2 * q)) - 1u;
     uint32_t cnt = 0, racc = 0;
@@ -293,7 +332,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             x0 = ((f0 & o.fm) & (uint64_t)(int64_t)(int32_t)o.sm0) << (o.t4 & 60u);
             x1 = ((f1 & o.fm) & (uint64_t)(int64_t)(int32_t)o.sm1) << (o.t4 & 60u);
         }
-        if constexpr (MODE == MODE_FILTER_BITS) {
+        if constexpr (mode_bit_compare(MODE)) {
             if constexpr (ETYPE == CVEC_F32) { st0 ^= x0; st1 ^= x1; x0 = st0; x1 = st1; }
             else { x0 ^= tgt; x1 ^= tgt; }
             // zero word = match: count the mismatches (min(x, 1)), no compare / carry instructions
@@ -303,7 +342,12 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             else { w0 = (uint32_t)x0 | (uint32_t)(x0 >> 32); w1 = (uint32_t)x1 | (uint32_t)(x1 >> 32); }
             asm("v_min_u32 %0, 1, %1" : "=v"(m0) : "v"(w0));
             asm("v_min_u32 %0, 1, %1" : "=v"(m1) : "v"(w1));
-            mism += m0 + m1;
+            if constexpr (MODE == MODE_FILTER_BITS) {
+                mism += m0 + m1;
+            } else {
+                if (k < 16) { acc_lo |= m0 << (2 * k); acc_lo |= m1 << (2 * k + 1); }
+                else { acc_hi |= m0 << (2 * k - 32); acc_hi |= m1 << (2 * k - 31); }
+            }
             return;
         }
         if constexpr (ETYPE == CVEC_F32) {
@@ -315,18 +359,11 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         // ---- epilogue ----------------------------------------------------------------------------------------
         if constexpr (MODE == MODE_FILTER || MODE == MODE_FILTER_MASKS) {
             const bool m0 = pred_match<ETYPE, NPRED>(pa, x0), m1 = pred_match<ETYPE, NPRED>(pa, x1);
-            cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
             if constexpr (MODE == MODE_FILTER_MASKS) {
-                // byte k of the section's mask: bits 2q, 2q+1 from each lane of the quad
-                uint32_t bits = zeroes ? (pa.match_zero ? 3u : 0u) : ((m0 ? 1u : 0u) | (m1 ? 2u : 0u));
-                if (kind == K_GATED) bits = 0;
-                bits <<= 2 * q;
-                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
-                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
-                // lane q of the quad collects mask bytes 4q..4q+3 and 16+4q..16+4q+3 (dwords q and 4+q of
-                // the section's mask); the caller stores them once per chunk
-                const uint32_t mine = q == (uint32_t)((k >> 2) & 3) ? bits : 0u;
-                if (k < 16) mask_lo |= mine << (8 * (k & 3)); else mask_hi |= mine << (8 * (k & 3));
+                const uint32_t bits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u);
+                if (k < 16) acc_lo |= bits << (2 * k); else acc_hi |= bits << (2 * k - 32);
+            } else {
+                cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
             }
         } else {
             if (addc) {
@@ -383,7 +420,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         prev = cur;
         // the next header has landed once only this iteration's field reads are outstanding; the
         // step's results pass through the wait so that the work above is issued ahead of it
-        asm volatile("s_waitcnt lgkmcnt(%c6)" : "+v"(mask_n), "+v"(nw_n), "+v"(cnt), "+v"(mism), "+v"(st0), "+v"(st1) : "i"(NDATA) : "memory");
+        if constexpr (mode_has_masks(MODE))
+            asm volatile("s_waitcnt lgkmcnt(%c6)" : "+v"(mask_n), "+v"(nw_n), "+v"(acc_lo), "+v"(acc_hi), "+v"(st0), "+v"(st1) : "i"(NDATA) : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(%c6)" : "+v"(mask_n), "+v"(nw_n), "+v"(cnt), "+v"(mism), "+v"(st0), "+v"(st1) : "i"(NDATA) : "memory");
         mask = mask_n; nw = nw_n;
     }
     back(prev, FIXED_LEN / 8 - 1, std::integral_constant<int, 0>());
@@ -397,6 +437,14 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         count = FIXED_LEN;
     } else {
         if constexpr (MODE == MODE_FILTER_BITS) cnt = 2 * (FIXED_LEN / 8) - mism; // the lane saw 64 elements
+        if constexpr (mode_has_masks(MODE)) {
+            if constexpr (MODE == MODE_FILTER_MASKS_BITS) { acc_lo = ~acc_lo; acc_hi = ~acc_hi; }
+            // null_mask() / a section behind a closed gate
+            if (zeroes) acc_lo = acc_hi = pa.match_zero ? ~0u : 0u;
+            if (kind == K_GATED) acc_lo = acc_hi = 0u;
+            quad_mask_bytes(acc_lo, acc_hi, q, mask_lo, mask_hi);
+            cnt = (uint32_t)__popc(mask_lo) + (uint32_t)__popc(mask_hi);
+        }
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
         // null_mask(): all ones iff the predicate matches zero (src/filter.rs:104-106)
@@ -426,7 +474,7 @@ __device__ inline void section_exact(const uint8_t *data, uint32_t lds_base, uin
     const uint32_t p0 = rel + (kind == K_DELTA ? (uint32_t)DELTA_HDR : (kind == K_RAW ? 0u : 3u));
     const uint32_t base = kind == K_DELTA ? lds_load_unaligned<4>(lds_base + rel + 4u) : 0u;
     const bool addc = sa.add_const != 0;
-    uint32_t st0 = 0, st1 = 0, cnt = 0, hmax = 0, p = p0;
+    uint32_t st0 = 0, st1 = 0, cnt = 0, hmax = 0, p = p0, acc_lo = 0, acc_hi = 0;
     mask_lo = 0; mask_hi = 0;
     for (uint32_t k = 0; k < (uint32_t)FIXED_LEN / 8; k++) {
         const uint32_t m = data[p], nw = data[p + 1];
@@ -460,12 +508,9 @@ __device__ inline void section_exact(const uint8_t *data, uint32_t lds_base, uin
         } else {
             const bool m0 = pred_match<ETYPE, NPRED>(pa, x[0]), m1 = pred_match<ETYPE, NPRED>(pa, x[1]);
             cnt += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
-            if constexpr (MODE == MODE_FILTER_MASKS) {
-                uint32_t bits = ((m0 ? 1u : 0u) | (m1 ? 2u : 0u)) << (2u * q);
-                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
-                bits |= __builtin_amdgcn_update_dpp(0u, bits, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
-                const uint32_t mine = q == ((k >> 2) & 3u) ? bits : 0u;
-                if (k < 16) mask_lo |= mine << (8u * (k & 3u)); else mask_hi |= mine << (8u * (k & 3u));
+            if constexpr (mode_has_masks(MODE)) {
+                const uint32_t bits = (m0 ? 1u : 0u) | (m1 ? 2u : 0u);
+                if (k < 16) acc_lo |= bits << (2u * k); else acc_hi |= bits << (2u * k - 32u);
             }
         }
         p += m ? (n4 * pc + 20u) >> 3 : 1u;
@@ -474,6 +519,7 @@ __device__ inline void section_exact(const uint8_t *data, uint32_t lds_base, uin
     if (p > end || hmax > 7) status = walk_status<4>(data, p0, end, kind == K_RAW);
     uint32_t count = FIXED_LEN;
     if constexpr (MODE != MODE_DECODE) {
+        if constexpr (mode_has_masks(MODE)) quad_mask_bytes(acc_lo, acc_hi, q, mask_lo, mask_hi);
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
         cnt += __builtin_amdgcn_update_dpp(0u, cnt, 0x4e /* quad_perm:[2,3,0,1] */, 0xf, 0xf, true);
         count = cnt;

@@ -257,13 +257,10 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
             wbase = nwbase;
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MODE == MODE_FILTER_MASKS) {
+        if constexpr (mode_has_masks(MODE)) {
             // the masks of the last pass leave behind the wait for the staged bytes (a store in flight in front
             // of that wait would add its round trip to it)
-            if (mk_pending) {
-                uint32_t *m = (uint32_t *)(masks + (uint64_t)mk_slot * 32) + q;
-                m[0] = mks_lo; m[4] = mks_hi;
-            }
+            if (mk_pending) *(uint2 *)(masks + (uint64_t)mk_slot * 32 + 8u * q) = uint2{mks_lo, mks_hi};
             mk_pending = false;
         }
         VS_PROBE(0);
@@ -401,10 +398,9 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
                     } else {
                         const bool all = b0 == K_NULL ? pa.match_zero != 0 : pred_match<ETYPE, NPRED>(pa, v);
                         cnt += all ? r * (uint32_t)FIXED_LEN : 0u;
-                        if constexpr (MODE == MODE_FILTER_MASKS) {
+                        if constexpr (mode_has_masks(MODE)) {
                             for (uint32_t j = 0; j < r; j++) {
-                                uint32_t *m = (uint32_t *)(masks + (uint64_t)(slot + j) * 32) + q;
-                                m[0] = m[4] = all ? ~0u : 0u;
+                                *(uint2 *)(masks + (uint64_t)(slot + j) * 32 + 8u * q) = all ? uint2{~0u, ~0u} : uint2{0u, 0u};
                             }
                         }
                     }
@@ -530,7 +526,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
             else {
                 cnt += res_word & 0xffffu;
                 kvalid++;
-                if constexpr (MODE == MODE_FILTER_MASKS) { mk_pending = true; mk_slot = slot0 + k; mks_lo = mk_lo; mks_hi = mk_hi; }
+                if constexpr (mode_has_masks(MODE)) { mk_pending = true; mk_slot = slot0 + k; mks_lo = mk_lo; mks_hi = mk_hi; }
             }
             pos = pos_after;
             k++;
@@ -542,11 +538,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
             break;
         }
     }
-    if constexpr (MODE == MODE_FILTER_MASKS) {
-        if (mk_pending) {
-            uint32_t *m = (uint32_t *)(masks + (uint64_t)mk_slot * 32) + q;
-            m[0] = mks_lo; m[4] = mks_hi;
-        }
+    if constexpr (mode_has_masks(MODE)) {
+        if (mk_pending) *(uint2 *)(masks + (uint64_t)mk_slot * 32 + 8u * q) = uint2{mks_lo, mks_hi};
     }
     VS_PROBE_FLUSH;
     // ---- the wave's totals ------------------------------------------------------------------------------------------------------
@@ -616,13 +609,16 @@ static void launch_vstream_t(int mode, const cvec_dbatch_view &b, const PredArgs
     default: CVEC_VS(M, 16); break;                                                                                        \
     }
     if (mode == MODE_DECODE) CVEC_VS(MODE_DECODE, 1);
-    else if (d_masks) { CVEC_VS_BUCKET(MODE_FILTER_MASKS); }
     else if (bucket == 1) {
         // bit-pattern equality is IEEE == unless the predicate is a float zero or NaN
         const uint32_t fb = (uint32_t)pa.v[0];
         const bool bits_ok = ETYPE != CVEC_F32 || ((fb & 0x7fffffffu) != 0 && (fb & 0x7fffffffu) <= 0x7f800000u);
-        if (bits_ok) CVEC_VS(MODE_FILTER_BITS, 1); else CVEC_VS(MODE_FILTER, 1);
-    } else {
+        if (d_masks) { if (bits_ok) CVEC_VS(MODE_FILTER_MASKS_BITS, 1); else CVEC_VS(MODE_FILTER_MASKS, 1); }
+        else if (bits_ok) CVEC_VS(MODE_FILTER_BITS, 1);
+        else CVEC_VS(MODE_FILTER, 1);
+    }
+    else if (d_masks) { CVEC_VS_BUCKET(MODE_FILTER_MASKS); }
+    else {
         CVEC_VS_BUCKET(MODE_FILTER);
     }
 #undef CVEC_VS_BUCKET
