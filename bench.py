@@ -196,10 +196,13 @@ def main():
 
     # ---- correctness gate before timing: the count must equal a direct count on the raw values ----------
     distinct = torch.unique(values[:1 << 20])
-    check_pred = float(distinct[distinct.numel() // 2].item())   # a value that does occur
+    check_pred_t = distinct[distinct != 0][distinct.numel() // 2].reshape(1).clone()   # a value that does occur
+    if use_dist:
+        dist.broadcast(check_pred_t, 0)                          # every rank checks the same value
+    check_pred = float(check_pred_t.item())
     got = batch.filter_count(check_pred)
-    want = int((values == check_pred).sum().item())
-    assert got == want and got > 0, "filter count %d != %d" % (got, want)
+    want_occ = int((values == check_pred).sum().item())
+    assert got == want_occ and (got > 0 or rank != 0), "filter count %d != %d" % (got, want_occ)
     want_timed = int((values == PRED).sum().item())
 
     pred = cv.make_pred(cv.F32, PRED)
@@ -267,6 +270,25 @@ def main():
         dist.all_reduce(wt, op=dist.ReduceOp.SUM)
         want_timed = int(wt.item())
     assert total_count == want_timed, "timed predicate count %d != %d" % (total_count, want_timed)
+    # The reference's predicate (3.0) never occurs in this generator's k / 1.4 values, so the comparison above is
+    # 0 == 0.  Behind the clock, the same path (ring, streams, workspaces, collective) runs once per stream with a
+    # value that does occur, and every one of those steps has to count what a direct count on the values gives.
+    pred_occ = cv.make_pred(cv.F32, check_pred)
+    if use_dist:
+        wo = torch.tensor([want_occ], device="cuda", dtype=torch.int64)
+        dist.all_reduce(wo, op=dist.ReduceOp.SUM)
+        want_occ = int(wo.item())
+    occ_rows = []
+    for _ in range(nstreams):
+        row, si = ring.begin_step()
+        with torch.cuda.stream(streams[si]):
+            views[si].filter_count_async(pred_occ, result=row)
+        occ_rows.append(ring.end_step())
+    drain()
+    torch.cuda.synchronize()
+    occ_counts = [int(results[r][0].item()) for r in occ_rows]
+    assert all(c == want_occ for c in occ_counts) and want_occ > 0, \
+        "occurring predicate %r: counts %r != %d" % (check_pred, occ_counts, want_occ)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * raw_bytes * args.steps / elapsed / 1e9
@@ -293,7 +315,12 @@ def main():
                    "vectors_per_gpu": nvec, "vector_len": VEC_LEN, "parallelism": "shard%d" % world,
                    "steps_in_flight": nstreams, "prewarm_passes": args.prewarm,
                    "compressed_bytes_per_gpu": batch.n_bytes,
-                   "compressed_bytes_per_element": round(batch.n_bytes / n_elems, 4)},
+                   "compressed_bytes_per_element": round(batch.n_bytes / n_elems, 4),
+                   "tail_rule": "format (every octet decodes to what was encoded; extra.reference_tail_rule has "
+                                "the reference crate's tail decoder on the same step)"},
+        "checks": {"timed_predicate": PRED, "timed_count": total_count, "timed_count_expected": want_timed,
+                   "occurring_predicate": check_pred, "occurring_counts_same_path": occ_counts,
+                   "occurring_count_expected": want_occ},
     }
     if rank == 0:
         traffic = None
@@ -316,15 +343,21 @@ def main():
             cb, cpu_total = cpu_baseline(batch, 4096, args.cpu_seconds, PRED)
             out["cpu_baseline"] = cb
         if not args.no_extra and world == 1:
-            out["extra"] = side_measurements(torch, cv, batch, values, elem_off, raw_bytes)
+            out["extra"] = side_measurements(torch, cv, batch, values, elem_off, raw_bytes, check_pred)
             out["extra"]["first_encode_call_s"] = round(t_first_encode, 4)
             if not args.no_configs:
                 del values, batch
                 torch.cuda.empty_cache()
                 out["extra"]["configs"] = config_table(torch, cv, N)
-                # every configuration's count against a direct count on its values: a false one means a kernel
-                # gave wrong results at full size, whatever its throughput says
-                out["extra"]["all_configs_exact"] = all(r["filter_count_equals_direct_count"] for r in out["extra"]["configs"])
+                out["extra"]["operations"] = operation_table(torch, cv)
+                # every configuration's counts (the reference's predicate and a value that occurs), masks and decoded
+                # values against the values themselves: a false one means a kernel gave wrong results at full size,
+                # whatever its throughput says
+                out["extra"]["all_configs_exact"] = all(r["filter_count_equals_direct_count"] and r["exact"]["all"]
+                                                        for r in out["extra"]["configs"]) and \
+                    all(v.get("exact", True) for v in out["extra"]["operations"].values() if isinstance(v, dict)) and \
+                    all(out["extra"][k] for k in ("decode_bit_exact_vs_input", "filter_two_steps_in_flight_exact",
+                                                  "filter_resident_index_same_count"))
                 if not out["extra"]["all_configs_exact"]:
                     print("bench.py: a configuration's filter count differs from the direct count (see extra.configs)",
                           file=sys.stderr, flush=True)
@@ -344,7 +377,7 @@ def _time_gpu(torch, fn, iters):
     return (time.perf_counter() - t0) / iters
 
 
-def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
+def side_measurements(torch, cv, batch, values, elem_off, raw_bytes, check_pred):
     """Reported next to the headline, outside the timed region: decode through the sink stack into a
     buffer, encode, and the host-inclusive (pinned H2D / D2H) filter rate."""
     ex = {}
@@ -375,13 +408,36 @@ def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
     t0 = time.perf_counter()
     two_in_flight(40)
     ex["filter_two_steps_in_flight_GBs"] = round(raw_bytes * 40 / (time.perf_counter() - t0) / 1e9, 2)
+    # the same two streams and workspaces with a value that occurs: both results against a direct count
+    want_occ = int((values == check_pred).sum().item())
+    pred_occ = cv.make_pred(cv.F32, check_pred)
+    pred, pred_timed = pred_occ, pred
+    two_in_flight(4)
+    pred = pred_timed
+    ex["filter_two_steps_in_flight_exact"] = bool(want_occ > 0 and all(int(r[0].item()) == want_occ for r in results))
     # the same step over a batch that keeps its section index resident (the header walk done once, by
     # build_index(), instead of in every pass); the headline never uses it
     indexed = views[1].build_index()
     res = indexed.result_buffer()
     t = _time_gpu(torch, lambda: indexed.filter_count_async(pred, result=res), 40)
     ex["filter_resident_index_GBs"] = round(raw_bytes / t / 1e9, 2)
-    ex["filter_resident_index_same_count"] = bool(int(res.cpu()[0]) == int(batch.filter_count_async(pred).cpu()[0]))
+    indexed.filter_count_async(pred_occ, result=res)
+    ex["filter_resident_index_same_count"] = bool(int(res.cpu()[0]) == want_occ)
+    # the reference crate's tail decoder (cvec_read_options.tail_rule) on the headline step: same kernels with the
+    # rule fused in; its count of the occurring value differs from the format's rule by the matches that the crate
+    # drops in the last octets of a vector
+    plain = cv.DeviceBatch(batch.etype, batch.d_bytes, batch.d_byte_off, batch.d_sec_base, batch.n_vectors,
+                           batch.n_sections, batch.n_bytes)
+    res2 = plain.result_buffer()
+    t_fmt = _time_gpu(torch, lambda: plain.filter_count_async(pred, result=res2, tail_rule="format"), 40)
+    t_ref = _time_gpu(torch, lambda: plain.filter_count_async(pred, result=res2, tail_rule="reference"), 40)
+    plain.filter_count_async(pred_occ, result=res2, tail_rule="reference")
+    ref_occ = int(res2.cpu()[0])
+    ex["reference_tail_rule"] = {"filter_GBs": round(raw_bytes / t_ref / 1e9, 2),
+                                 "format_rule_same_call_GBs": round(raw_bytes / t_fmt / 1e9, 2),
+                                 "occurring_count": ref_occ, "occurring_count_format_rule": want_occ,
+                                 "note": "parity of this rule rests on the oracle's reading of "
+                                         "src/nibblepack_simd.rs:433-450, :546-554 (no reference fixture covers it)"}
     # ingest through the series appender: the same values arrive as scrapes of 64 per vector, sections are encoded as
     # they complete, finish() must give the batch that encode_all gave
     n_vec, vec_len, k = batch.n_vectors, values.numel() // batch.n_vectors, 64
@@ -440,6 +496,79 @@ def side_measurements(torch, cv, batch, values, elem_off, raw_bytes):
     return ex
 
 
+def _popcount_u8(torch, t):
+    """Number of set bits of a uint8 tensor."""
+    x = t.view(torch.int32) if t.numel() % 4 == 0 else t.to(torch.int32)
+    x = x - ((x >> 1) & 0x55555555)
+    x = (x & 0x33333333) + ((x >> 2) & 0x33333333)
+    x = (x + (x >> 4)) & 0x0f0f0f0f
+    return ((x * 0x01010101) >> 24 & 0xff).sum()
+
+
+def operation_table(torch, cv):
+    """The operations around the single-vector filter, at the shapes of the reference's benches: MultiVectorFilter
+    over a dense and a very sparse u32 column in both orders (benches/bench.rs:192-203), match_positions
+    (src/filter.rs:302-321), the legacy stream codecs (src/nibblepacking.rs:15-45, :239-325).  Rates in GB/s of
+    uncompressed values touched per call (wall time, Python included); every result is checked against a direct
+    computation on the values."""
+    from compressed_vec_amd import stream, synth
+    ops = {}
+    nvec, length = 26214, 10000
+    chunks = [synth.batch_values_torch("u32_dense", min(4096, nvec - c0), length, v_first=c0)[0] for c0 in range(0, nvec, 4096)]
+    dense_v = torch.cat(chunks)
+    del chunks
+    keep = torch.zeros(length, dtype=torch.bool, device="cuda")
+    keep[2475:2525] = True
+    keep[7475:7525] = True
+    # (the sparse column's values are the dense generator's at another phase, with 15 beside every other 3 of the
+    # dense column, so that some rows match in both columns)
+    idx = torch.arange(dense_v.numel(), device="cuda")
+    sparse_v = torch.where((dense_v == 3) & (idx % 2 == 0), torch.full_like(dense_v, 15), torch.roll(dense_v, 1234))
+    sparse_v = torch.where(keep.repeat(nvec), sparse_v, torch.zeros_like(dense_v))
+    del idx
+    eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * length
+    dense = cv.encode_device("u32", dense_v, eo)
+    sparse = cv.encode_device("u32", sparse_v, eo)
+    raw2 = 2 * dense_v.numel() * 4
+    want = int(((dense_v == 3) & (sparse_v == 15)).sum().item())
+    for name, cols, preds in (("multi_filter_dense_then_sparse", [dense, sparse], [3, 15]),
+                              ("multi_filter_sparse_then_dense", [sparse, dense], [15, 3])):
+        got = cv.multi_filter(cols, preds)
+        t = _time_gpu(torch, lambda: cv.multi_filter(cols, preds), 10)
+        ops[name] = {"GBs": round(raw2 / t / 1e9, 1), "ms": round(t * 1e3, 4), "count": got, "count_expected": want,
+                     "exact": bool(got == want and want > 0),
+                     "shape": "2 columns x %d vectors x %d u32 (bench.rs:192-203: == 3 on the dense, == 15 on the sparse)" % (nvec, length)}
+    fc = dense.filter_masks(3)
+    pos, off = fc.match_positions()
+    want_pos = int((dense_v == 3).sum().item())
+    first = torch.nonzero(dense_v[:length] == 3).view(-1).cpu().numpy()
+    t = _time_gpu(torch, lambda: fc.match_positions(), 5)
+    ops["match_positions"] = {"ms": round(t * 1e3, 3), "positions": int(off[-1]), "positions_per_s": round(int(off[-1]) / t, 0),
+                              "exact": bool(int(off[-1]) == want_pos and np.array_equal(pos[:int(off[1])], first)),
+                              "shape": "%d vectors x %d u32, == 3; positions copied to the host in the timed call" % (nvec, length)}
+    del dense, sparse, dense_v, sparse_v, fc
+    torch.cuda.empty_cache()
+    n, length = 13107, 10000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    inc = torch.cumsum(torch.randint(0, 1000, (n, length), device="cuda", generator=g, dtype=torch.int64), dim=1).reshape(-1)
+    flt = (torch.randn(n * length, device="cuda", generator=g, dtype=torch.float64) * 100).view(torch.int64)
+    seo = torch.arange(n + 1, device="cuda", dtype=torch.int64) * length
+    raw = n * length * 8
+    for kind, d_vals in (("u64_delta", inc), ("f64_xor", flt)):
+        d_bytes, d_bo, _, d_res = stream.pack_device(kind, d_vals, seo, n * length)
+        nb = int(d_res.cpu()[0])
+        t_p = _time_gpu(torch, lambda: stream.pack_device(kind, d_vals, seo, n * length), 5)
+        back = stream.unpack_device(kind, d_bytes, d_bo, nb, seo, n * length)
+        t_u = _time_gpu(torch, lambda: stream.unpack_device(kind, d_bytes, d_bo, nb, seo, n * length), 5)
+        out = back[0] if isinstance(back, (tuple, list)) else back
+        ops["stream_" + kind] = {"pack_GBs": round(raw / t_p / 1e9, 1), "unpack_GBs": round(raw / t_u / 1e9, 1),
+                                 "packed_B_per_value": round(nb / (n * length), 3),
+                                 "exact": bool(torch.equal(out.view(torch.int64)[:n * length], d_vals)),
+                                 "shape": "%d streams x %d values of 8 bytes" % (n, length)}
+    return ops
+
+
 def config_table(torch, cv, N):
     """The reference's `cargo bench vector` configurations (benches/bench.rs:131-170) as batches of 1 GiB
     of uncompressed values, and both data sets at the headline shape: for each, encode_all, decode through
@@ -489,9 +618,28 @@ def config_table(torch, cv, N):
         p = cv.make_pred(batch.etype, pred)
         want = int((vals == pred).sum().item())
         t_dec = _time_gpu(torch, lambda: batch.decode_async(out, add_const=add_const), 10)
+        # bit for bit (vectors are padded to whole sections in the output)
+        dec_ok = bool(torch.equal(out.view(nvec, -1)[:, :length].contiguous().view(-1).view(torch.uint8),
+                                  (vals + add_const).view(torch.uint8)))
         t_fil = _time_gpu(torch, lambda: batch.filter_count_async(p, result=res), 30)
         got = int(res[0].item())
         t_msk = _time_gpu(torch, lambda: batch.filter_count_async(p, result=res, masks=masks), 10)
+        # a value that occurs (the reference's predicates 3.0 never do in the f32 data): count-only pass, mask pass
+        # (its count and the bits of its masks) against a direct comparison on the values
+        nz = vals[:1 << 22]
+        occ = nz[nz != 0][7].item()
+        want_occ = int((vals == occ).sum().item())
+        po = cv.make_pred(batch.etype, occ)
+        batch.filter_count_async(po, result=res)
+        got_occ = int(res[0].item())
+        batch.filter_count_async(po, result=res, masks=masks)
+        got_occ_m = int(res[0].item())
+        pop = int(_popcount_u8(torch, masks))
+        exact = {"reference_predicate": bool(got == want), "occurring_predicate": occ, "occurring_count": got_occ,
+                 "occurring_count_expected": want_occ, "mask_pass_count": got_occ_m, "mask_bits_set": pop,
+                 "decode_equals_values_plus_const": dec_ok}
+        exact["all"] = bool(got == want and got_occ == want_occ and got_occ_m == want_occ and pop == want_occ and
+                            want_occ > 0 and dec_ok)
         k_fil = kernel_ms(lambda: batch.filter_count_async(p, result=res), 20)
         k_dec = kernel_ms(lambda: batch.decode_async(out, add_const=add_const), 10)
         dom = max(k_fil)
@@ -508,7 +656,8 @@ def config_table(torch, cv, N):
                      # decode moves the compressed bytes in and the uncompressed bytes out
                      "decode_roofline_frac": round((raw + batch.n_bytes) / (max(k_dec) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                      if max(k_dec) > 0 else None,
-                     "filter_count_equals_direct_count": bool(got == want)})
+                     "filter_count_equals_direct_count": bool(got == want and got_occ == want_occ),
+                     "exact": exact})
         del vals, batch, out, masks
         torch.cuda.empty_cache()
 

@@ -54,6 +54,28 @@ class DBatchView(C.Structure):
                 ("d_sec_base", C.c_void_p)]
 
 
+class ReadOptions(C.Structure):
+    """cvec_read_options: what one read call runs with (-1 = the process-wide default)."""
+    _fields_ = [("read_path", C.c_int32), ("tail_rule", C.c_int32), ("indexed", C.c_int32), ("_pad", C.c_int32),
+                ("d_gate", C.c_void_p)]
+
+
+OPT_DEFAULT = -1
+_PATHS = {None: OPT_DEFAULT, "auto": PATH_AUTO, "slots": PATH_SLOTS, "vstream": PATH_VSTREAM}
+_TAILS = {None: OPT_DEFAULT, "format": TAIL_FORMAT, "reference": TAIL_REFERENCE}
+
+
+def read_options(read_path=None, tail_rule=None, indexed=False, gate_ptr=None):
+    """A ReadOptions from names: read_path None | "auto" | "slots" | "vstream", tail_rule None | "format" |
+    "reference" (None = the process-wide default)."""
+    o = ReadOptions()
+    o.read_path = _PATHS[read_path] if not isinstance(read_path, int) else read_path
+    o.tail_rule = _TAILS[tail_rule] if not isinstance(tail_rule, int) else tail_rule
+    o.indexed = 1 if indexed else 0
+    o.d_gate = gate_ptr
+    return o
+
+
 class MaskColumn(C.Structure):
     _fields_ = [("d_masks", C.c_void_p), ("d_sec_base", C.c_void_p), ("d_valid", C.c_void_p),
                 ("n_sections", C.c_uint64)]
@@ -70,6 +92,15 @@ SIGNATURES = {
     "cvec_status_name": (C.c_char_p, [C.c_int32]),
     "cvec_set_read_path": (C.c_int32, [C.c_int32]),
     "cvec_set_tail_rule": (C.c_int32, [C.c_int32]),
+    "cvec_read_options_effective": (C.c_int32, [C.POINTER(ReadOptions), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cvec_filter_count_opt_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(Pred), C.POINTER(ReadOptions), C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_decode_opt_dev": (C.c_int32, [C.POINTER(DBatchView), C.POINTER(SinkChain), C.POINTER(ReadOptions), C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "cvec_filter_count_batch_opt": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Pred),
+                                                C.POINTER(ReadOptions), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p]),
+    "cvec_decode_batch_opt": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(SinkChain),
+                                          C.POINTER(ReadOptions), C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cvec_timing_begin": (C.c_int32, [C.c_int32]),
     "cvec_timing_end": (C.c_int32, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                     C.POINTER(C.c_int32)]),
@@ -159,7 +190,8 @@ _lib = None
 def set_tail_rule(rule):
     """"format" (default): every octet decodes by the bitstream rule of the wire format, i.e. to the values that
     were encoded.  "reference": the last octets of a vector decode the way the reference crate's tail fallback
-    does (cvec_set_tail_rule, CVEC_TAIL_REFERENCE).  Process-wide."""
+    does (cvec_set_tail_rule, CVEC_TAIL_REFERENCE).  The process-wide default; the read operations also take
+    tail_rule= per call."""
     check(lib().cvec_set_tail_rule({"format": TAIL_FORMAT, "reference": TAIL_REFERENCE}[rule]))
 
 

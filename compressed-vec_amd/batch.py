@@ -254,10 +254,13 @@ class DeviceBatch:
         self._keep_index = self._index_valid = True
         return self
 
-    def filter_count_async(self, pred, per_vector=None, status=None, masks=None, result=None, gate=None):
+    def filter_count_async(self, pred, per_vector=None, status=None, masks=None, result=None, gate=None,
+                           tail_rule=None, read_path=None):
         """Enqueues decode+filter+count on the current stream; returns the device result tensor
         (int64[4]: total, failed vectors, max status, reserved).  `gate`: masks of an earlier pass over
-        a batch with the same section layout; sections whose gate mask is empty are not decoded."""
+        a batch with the same section layout; sections whose gate mask is empty are not decoded.
+        `tail_rule` ("format" | "reference") and `read_path` ("auto" | "slots" | "vstream") hold for this call
+        alone (cvec_read_options); None = the process-wide default."""
         res = result if result is not None else self.result_buffer()
         if isinstance(pred, (list, tuple, np.ndarray)) and len(pred) > N.MAX_PRED_VALUES:
             # OneOf over a large set (the reference's set is a Vec, src/filter.rs:143-160): one pass per 16 values
@@ -274,6 +277,15 @@ class DeviceBatch:
         ws = self.workspace()
         if self._keep_index and not self._index_valid:
             self.build_index()                  # an unindexed pass used the workspace since: walk the headers again
+        if tail_rule is not None or read_path is not None:
+            indexed = bool(self._keep_index and self._index_valid)
+            o = N.read_options(read_path, tail_rule, indexed, gate.data_ptr() if gate is not None else None)
+            with torch.cuda.device(self.device):
+                N.check(N.lib().cvec_filter_count_opt_dev(C.byref(self.view), C.byref(p), C.byref(o), _ptr(res),
+                                                          _ptr(per_vector), _ptr(status), _ptr(masks), _ptr(ws),
+                                                          ws.numel(), _stream_ptr()))
+            self._index_valid = indexed
+            return res
         with torch.cuda.device(self.device):
             if self._keep_index and self._index_valid:
                 N.check(N.lib().cvec_filter_count_indexed_dev(C.byref(self.view), C.byref(p), _ptr(gate), _ptr(res),
@@ -286,11 +298,12 @@ class DeviceBatch:
                 self._index_valid = False       # only cvec_index_dev and the indexed calls keep an index
         return res
 
-    def filter_count(self, pred, per_vector=False, return_status=False, return_masks=False):
+    def filter_count(self, pred, per_vector=False, return_status=False, return_masks=False, tail_rule=None,
+                     read_path=None):
         pv = torch.empty(self.n_vectors, dtype=torch.int64, device=self.device) if per_vector else None
         st = torch.empty(self.n_vectors, dtype=torch.int32, device=self.device) if return_status else None
         mk = torch.zeros(self.n_sections * 32, dtype=torch.uint8, device=self.device) if return_masks else None
-        res = self.filter_count_async(pred, pv, st, mk).cpu().numpy()
+        res = self.filter_count_async(pred, pv, st, mk, tail_rule=tail_rule, read_path=read_path).cpu().numpy()
         if res[1] and not return_status:
             raise N.CodingError(int(res[2]), "%d vector(s) failed" % int(res[1]))
         out = [int(res[0])]
@@ -320,12 +333,21 @@ class DeviceBatch:
                                                     _stream_ptr()))
         return FilteredColumn(self, masks, valid, res.clone())
 
-    def decode_async(self, out, add_const=None, status=None, result=None):
-        """Enqueues decode through [AddConstSink →] VecSink into `out` (256 * n_sections elements)."""
+    def decode_async(self, out, add_const=None, status=None, result=None, tail_rule=None, read_path=None):
+        """Enqueues decode through [AddConstSink →] VecSink into `out` (256 * n_sections elements).  `tail_rule`,
+        `read_path`: as for filter_count_async."""
         assert out.numel() >= self.n_sections * FIXED_LEN and out.element_size() == WIDTH[self.etype]
         chain = make_chain(self.etype, add_const)
         ws = self.workspace()
         res = result if result is not None else self.result_buffer()
+        if tail_rule is not None or read_path is not None:
+            indexed = bool(self._keep_index and self._index_valid)
+            o = N.read_options(read_path, tail_rule, indexed)
+            with torch.cuda.device(self.device):
+                N.check(N.lib().cvec_decode_opt_dev(C.byref(self.view), C.byref(chain), C.byref(o), _ptr(out), _ptr(res),
+                                                    _ptr(status), _ptr(ws), ws.numel(), _stream_ptr()))
+            self._index_valid = indexed
+            return res
         with torch.cuda.device(self.device):
             indexed = self._keep_index and self._index_valid
             fn = N.lib().cvec_decode_indexed_dev if indexed else N.lib().cvec_decode_dev
@@ -354,11 +376,11 @@ class DeviceBatch:
         stop = n if stop is None else min(stop, n)
         return out[start:stop]
 
-    def decode(self, add_const=None, return_status=False):
+    def decode(self, add_const=None, return_status=False, tail_rule=None, read_path=None):
         """Returns (values, out_off): every vector padded to whole sections, vectors back to back."""
         out = torch.zeros(self.n_sections * FIXED_LEN, dtype=TORCH_DTYPE[self.etype], device=self.device)
         st = torch.empty(self.n_vectors, dtype=torch.int32, device=self.device) if return_status else None
-        res = self.decode_async(out, add_const, st).cpu().numpy()
+        res = self.decode_async(out, add_const, st, tail_rule=tail_rule, read_path=read_path).cpu().numpy()
         if res[1] and not return_status:
             raise N.CodingError(int(res[2]), "%d vector(s) failed" % int(res[1]))
         vals = out.cpu().numpy().view(NP_DTYPE[self.etype])

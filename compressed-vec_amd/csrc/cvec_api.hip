@@ -36,6 +36,10 @@ void set_read_path(int path);
 hipError_t debug_sections_times(uint64_t *h_out);
 #endif
 void set_tail_rule(int rule);
+void set_call_options(int path, int tail);
+void get_call_options(int *path, int *tail);
+int effective_read_path();
+int effective_tail_rule();
 hipError_t launch_error_detail(int etype, const uint8_t *bytes, const uint64_t *byte_off, uint64_t n, const int32_t *status,
                                const uint32_t *valid, const uint8_t *parse_failed, uint64_t *detail, hipStream_t stream);
 hipError_t launch_merge_filter_pass(uint64_t n_vectors, uint64_t n_sections, const uint64_t *tmp_result,
@@ -432,6 +436,37 @@ cvec_status cvec_set_tail_rule(int32_t rule) {
     return CVEC_OK;
 }
 
+// The options of one call: valid values or CVEC_OPT_DEFAULT.
+static cvec_status check_options(const cvec_read_options *o) {
+    if (!o) return CVEC_OK;
+    if (o->read_path != CVEC_OPT_DEFAULT && o->read_path != PATH_AUTO && o->read_path != PATH_SLOTS && o->read_path != PATH_VSTREAM)
+        return CVEC_ERR_BAD_ARGUMENT;
+    if (o->tail_rule != CVEC_OPT_DEFAULT && o->tail_rule != CVEC_TAIL_FORMAT && o->tail_rule != CVEC_TAIL_REFERENCE)
+        return CVEC_ERR_BAD_ARGUMENT;
+    return CVEC_OK;
+}
+
+namespace {
+// Puts a call's options in force on this thread until the call returns (and restores what an enclosing call had set).
+struct CallOptions {
+    int old_path, old_tail;
+    explicit CallOptions(const cvec_read_options *o) {
+        get_call_options(&old_path, &old_tail);
+        if (o) set_call_options(o->read_path >= 0 ? o->read_path : old_path, o->tail_rule >= 0 ? o->tail_rule : old_tail);
+    }
+    ~CallOptions() { set_call_options(old_path, old_tail); }
+};
+} // namespace
+
+cvec_status cvec_read_options_effective(const cvec_read_options *opts, int32_t *read_path, int32_t *tail_rule) {
+    cvec_status st = check_options(opts);
+    if (st) return st;
+    CallOptions in_force(opts);
+    if (read_path) *read_path = effective_read_path();
+    if (tail_rule) *tail_rule = effective_tail_rule();
+    return CVEC_OK;
+}
+
 cvec_status cvec_timing_begin(int32_t max_records) {
     if (max_records <= 0 || max_records > 4096) return CVEC_ERR_BAD_ARGUMENT;
     HIP_TRY(timing_begin(max_records));
@@ -673,6 +708,16 @@ cvec_status cvec_filter_count_set_dev(const cvec_dbatch_view *batch, const uint6
     return CVEC_OK;
 }
 
+cvec_status cvec_filter_count_opt_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const cvec_read_options *opts,
+                                      uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                      void *d_workspace, size_t workspace_bytes, void *stream) {
+    cvec_status st = check_options(opts);
+    if (st) return st;
+    CallOptions in_force(opts);
+    return filter_count_phase(opts && opts->indexed ? READ_INDEXED : READ_ALL, batch, pred, opts ? opts->d_gate : nullptr,
+                              d_result, d_per_vector, d_status, d_masks, d_workspace, workspace_bytes, stream);
+}
+
 static cvec_status decode_phase(int phase, const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
                                 uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
                                 void *stream) {
@@ -706,6 +751,17 @@ cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_si
                                     uint64_t *d_result, int32_t *d_status, void *d_workspace,
                                     size_t workspace_bytes, void *stream) {
     return decode_phase(READ_INDEXED, batch, chain, d_out, d_result, d_status, d_workspace, workspace_bytes, stream);
+}
+
+cvec_status cvec_decode_opt_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, const cvec_read_options *opts,
+                                void *d_out, uint64_t *d_result, int32_t *d_status, void *d_workspace,
+                                size_t workspace_bytes, void *stream) {
+    cvec_status st = check_options(opts);
+    if (st) return st;
+    if (opts && opts->d_gate) return CVEC_ERR_BAD_ARGUMENT; // a gate belongs to a filter pass
+    CallOptions in_force(opts);
+    return decode_phase(opts && opts->indexed ? READ_INDEXED : READ_ALL, batch, chain, d_out, d_result, d_status,
+                        d_workspace, workspace_bytes, stream);
 }
 
 static_assert(CVEC_MAX_COLUMNS == CVEC_MAX_PRED_VALUES, "MaskColumns is sized by CVEC_MAX_PRED_VALUES");
@@ -914,6 +970,33 @@ cvec_status cvec_decode_batch(int32_t etype, const uint8_t *h_bytes, const uint6
                                    out_cap_elems, h_out_off);
     if (st) return st;
     return summary_status(r);
+}
+
+// The host-buffer calls with per-call options: the pipeline's kernels are launched by the calling thread, so the
+// options in force on it reach every chunk.  No gate and no resident index here (the batch lives in host memory).
+static cvec_status check_batch_options(const cvec_read_options *opts) {
+    cvec_status st = check_options(opts);
+    if (st) return st;
+    if (opts && (opts->d_gate || opts->indexed)) return CVEC_ERR_BAD_ARGUMENT;
+    return CVEC_OK;
+}
+
+cvec_status cvec_filter_count_batch_opt(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off,
+                                        uint64_t n_vectors, const cvec_pred *pred, const cvec_read_options *opts,
+                                        uint64_t *h_total, uint64_t *h_per_vector, int32_t *h_status) {
+    cvec_status st = check_batch_options(opts);
+    if (st) return st;
+    CallOptions in_force(opts);
+    return cvec_filter_count_batch(etype, h_bytes, h_byte_off, n_vectors, pred, h_total, h_per_vector, h_status);
+}
+
+cvec_status cvec_decode_batch_opt(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off, uint64_t n_vectors,
+                                  const cvec_sink_chain *chain, const cvec_read_options *opts, void *h_out,
+                                  uint64_t out_cap_elems, uint64_t *h_out_off, int32_t *h_status) {
+    cvec_status st = check_batch_options(opts);
+    if (st) return st;
+    CallOptions in_force(opts);
+    return cvec_decode_batch(etype, h_bytes, h_byte_off, n_vectors, chain, h_out, out_cap_elems, h_out_off, h_status);
 }
 
 static cvec_status encode_pipeline_body(SlotCache<EncSlot> *cache, int32_t etype, const void *h_values,

@@ -901,10 +901,18 @@ bool vstream_eligible(int mode, const cvec_dbatch_view &b, bool forced);
 hipError_t launch_vstream(int mode, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa, uint32_t *nvalid,
                           uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *d_out,
                           uint64_t *tag, hipStream_t stream);
-static int g_read_path = PATH_AUTO;
-void set_read_path(int path) { g_read_path = path; }
-static int g_tail_rule = 0; // 0: the format's bitstream rule; 1: the reference crate's tail decoder
-void set_tail_rule(int rule) { g_tail_rule = rule; }
+// Process-wide defaults (cvec_set_read_path, cvec_set_tail_rule) and the options of the entry point that is running
+// on this thread (cvec_*_opt_*: set for the duration of the call; -1 = the default applies).  A read operation is
+// launched by the thread that entered the library, so two threads can run with different options at once.
+static std::atomic<int> g_read_path{PATH_AUTO};
+static std::atomic<int> g_tail_rule{0}; // 0: the format's bitstream rule; 1: the reference crate's tail decoder
+static thread_local int t_read_path = -1, t_tail_rule = -1;
+void set_read_path(int path) { g_read_path.store(path, std::memory_order_relaxed); }
+void set_tail_rule(int rule) { g_tail_rule.store(rule, std::memory_order_relaxed); }
+void set_call_options(int path, int tail) { t_read_path = path; t_tail_rule = tail; }
+void get_call_options(int *path, int *tail) { *path = t_read_path; *tail = t_tail_rule; }
+int effective_read_path() { return t_read_path >= 0 ? t_read_path : g_read_path.load(std::memory_order_relaxed); }
+int effective_tail_rule() { return t_tail_rule >= 0 ? t_tail_rule : g_tail_rule.load(std::memory_order_relaxed); }
 
 template <int ETYPE>
 static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const PredArgs &pa, const SinkArgs &sa,
@@ -931,12 +939,13 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     // section kernel under the reference's tail rule
     uint8_t *const tail = (uint8_t *)(work + (size_t)(WORK_COUNTERS + 1) * WORK_STRIDE);
     const int rec = (g_timer.armed && g_timer.used < g_timer.capacity) ? g_timer.used++ : -1;
+    const int read_path = effective_read_path(), tail_rule = effective_tail_rule();
     // (the reference's tail rule needs the index pass's distances: the section-slot path)
-    if (phase == READ_ALL && d_gate == nullptr && g_read_path != PATH_SLOTS && g_tail_rule == 0) {
+    if (phase == READ_ALL && d_gate == nullptr && read_path != PATH_SLOTS && tail_rule == 0) {
         // sparse batches of many vectors: one kernel, no section index, no per-section results (the timing slots of
         // the index and finalize kernels hold the memset and nothing)
-        const bool vs = g_read_path == PATH_VSTREAM ? vstream_eligible(mode, b, true)
-                                                    : (g_read_path == PATH_AUTO && vstream_eligible(mode, b, false));
+        const bool vs = read_path == PATH_VSTREAM ? vstream_eligible(mode, b, true)
+                                                  : (read_path == PATH_AUTO && vstream_eligible(mode, b, false));
         if (vs) {
             timer_mark(rec, 0, stream);
             (void)hipMemsetAsync(d_result, 0, CVEC_RESULT_WORDS * sizeof(uint64_t), stream);
@@ -961,7 +970,7 @@ static void launch_read_t(int mode, int phase, const cvec_dbatch_view &b, const 
     if (phase != READ_INDEX_ONLY)
         launch_sections<ETYPE>(mode, b.d_bytes, desc, ns, pa, sa, sec_res, d_masks, d_out, check, cookie,
                                phase == READ_INDEXED ? d_gate : nullptr, b.n_bytes, work, epoch,
-                               g_tail_rule != 0 ? tail : nullptr, stream);
+                               tail_rule != 0 ? tail : nullptr, stream);
     timer_mark(rec, 3, stream);
     timer_mark(rec, 4, stream);
     if (n > 0 && phase != READ_INDEX_ONLY)

@@ -42,16 +42,19 @@ def encode_host(etype, values, elem_off, out=None):
     return EncodedBatch(etype, blob[:total.value], bo)
 
 
-def filter_count_host(batch, pred, per_vector=False, return_status=False):
-    """reader.filter_iter(pred) + count_hits for every vector of a host EncodedBatch."""
+def filter_count_host(batch, pred, per_vector=False, return_status=False, tail_rule=None, read_path=None):
+    """reader.filter_iter(pred) + count_hits for every vector of a host EncodedBatch.  `tail_rule` ("format" |
+    "reference") and `read_path` hold for this call alone (None = the process-wide default)."""
     n = batch.n_vectors
     L = N.lib()
     p = pred if isinstance(pred, N.Pred) else make_pred(batch.etype, pred)
     total = C.c_uint64(0)
     per = np.zeros(n, dtype=np.uint64) if per_vector else None
     st = np.zeros(n, dtype=np.int32) if return_status else None
-    rc = L.cvec_filter_count_batch(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(p), C.byref(total),
-                                   _p(per) if per is not None else None, _p(st) if st is not None else None)
+    o = N.read_options(read_path, tail_rule)
+    rc = L.cvec_filter_count_batch_opt(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(p), C.byref(o),
+                                       C.byref(total), _p(per) if per is not None else None,
+                                       _p(st) if st is not None else None)
     # 1..8 and ERR_SECTION_COUNT are "the largest per-vector status" (the statuses say which vectors);
     # anything above is a failure of the call as a whole
     if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT and st.any()):
@@ -64,7 +67,7 @@ def filter_count_host(batch, pred, per_vector=False, return_status=False):
     return out[0] if len(out) == 1 else tuple(out)
 
 
-def decode_host(batch, add_const=None, return_status=False, out=None):
+def decode_host(batch, add_const=None, return_status=False, out=None, tail_rule=None, read_path=None):
     """VectorReader::decode_to_sink through [AddConstSink ->] VecSink for every vector of a host
     EncodedBatch: (values padded to whole sections, out_off[n+1]) [+ status]."""
     n = batch.n_vectors
@@ -85,8 +88,9 @@ def decode_host(batch, add_const=None, return_status=False, out=None):
     out_off = np.zeros(n + 1, dtype=np.uint64)
     st = np.zeros(n, dtype=np.int32) if return_status else None
     chain = make_chain(batch.etype, add_const)
-    rc = L.cvec_decode_batch(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(chain), _p(vals), vals.size,
-                             _p(out_off), _p(st) if st is not None else None)
+    o = N.read_options(read_path, tail_rule)
+    rc = L.cvec_decode_batch_opt(batch.etype, _p(batch.blob), _p(batch.byte_off), n, C.byref(chain), C.byref(o), _p(vals),
+                                 vals.size, _p(out_off), _p(st) if st is not None else None)
     if rc != N.OK and not (return_status and rc <= N.ERR_SECTION_COUNT and st.any()):
         N.check(rc)
     return (vals, out_off, st) if return_status else (vals, out_off)

@@ -126,8 +126,8 @@ cvec_status cvec_timing_end(float *ms_index, float *ms_sections, float *ms_final
  *                      parallel over vectors, no index, each byte read once (u32 / f32, blob < 4 GiB);
  * CVEC_PATH_AUTO (default) picks VSTREAM for sparse batches (at least 16384 vectors, at most 64 sections per
  * vector and 48 bytes per section on average: mostly Null / Const sections), SLOTS otherwise.  Forcing
- * VSTREAM applies wherever the batch is eligible at all (gated and indexed passes, u64 batches and blobs of 4 GiB or more always take SLOTS).  Process-wide;
- * meant for tests and measurements. */
+ * VSTREAM applies wherever the batch is eligible at all (gated and indexed passes, u64 batches and blobs of 4 GiB or more always take SLOTS).  The setter changes the
+ * process-wide default; a single call chooses for itself through cvec_read_options. */
 enum { CVEC_PATH_AUTO = 0, CVEC_PATH_SLOTS = 1, CVEC_PATH_VSTREAM = 2 };
 cvec_status cvec_set_read_path(int32_t path);
 
@@ -140,9 +140,29 @@ cvec_status cvec_set_read_path(int32_t path);
  * values from there on).  Under this rule decode, counts, per-vector counts and masks of the _dev and _batch
  * read operations equal the crate's on well-formed vectors; passes take the section-slot kernels, which clear
  * the masks of such octets as they decode (no extra pass, no measurable cost).  The legacy stream codecs are not
- * affected.  Process-wide. */
+ * affected.  The setter changes the process-wide default; a single call chooses for itself through
+ * cvec_read_options. */
 enum { CVEC_TAIL_FORMAT = 0, CVEC_TAIL_REFERENCE = 1 };
 cvec_status cvec_set_tail_rule(int32_t rule);
+
+/* Options of ONE read call.  The reference's readers are shared by reference between threads (&self,
+ * src/vector.rs:392-464) and take everything that shapes a pass as arguments of the call; the two setters above are
+ * process-wide defaults, which two threads that want different rules cannot share.  The _opt entry points below take
+ * this struct instead: CVEC_OPT_DEFAULT in a field means "the process-wide default", a NULL struct means defaults
+ * throughout.  The options hold for that call alone, on the calling thread; concurrent calls with different options
+ * do not affect each other. */
+#define CVEC_OPT_DEFAULT (-1)
+typedef struct cvec_read_options {
+    int32_t read_path;     /* CVEC_PATH_* or CVEC_OPT_DEFAULT */
+    int32_t tail_rule;     /* CVEC_TAIL_* or CVEC_OPT_DEFAULT */
+    int32_t indexed;       /* nonzero: over the resident section index of the workspace (cvec_index_dev), as
+                              cvec_filter_count_indexed_dev / cvec_decode_indexed_dev */
+    int32_t _pad;
+    const uint8_t *d_gate; /* filter passes only, nullable: as cvec_filter_count_gated_dev */
+} cvec_read_options;
+/* What a call with these options would run with: the fields resolved against the process-wide defaults.
+ * CVEC_ERR_BAD_ARGUMENT for a field that is neither a valid value nor CVEC_OPT_DEFAULT.  Touches no device. */
+cvec_status cvec_read_options_effective(const cvec_read_options *opts, int32_t *read_path, int32_t *tail_rule);
 
 /* ---- device-resident operations ----------------------------------------------------------- */
 
@@ -194,6 +214,11 @@ cvec_status cvec_filter_count_set_dev(const cvec_dbatch_view *batch, const uint6
 cvec_status cvec_filter_count_static_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
                                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *stream);
 
+/* cvec_filter_count_dev / _gated_dev / _indexed_dev with the options of this call (see cvec_read_options). */
+cvec_status cvec_filter_count_opt_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, const cvec_read_options *opts,
+                                      uint64_t *d_result, uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks,
+                                      void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* The same, behind a gate: d_gate (nullable, 16-byte aligned) holds n_sections * 32 bytes, the masks
  * an earlier filter pass wrote for a batch with the same sec_base (e.g. the previous column of a
  * MultiVectorFilter).  A section whose gate mask is empty is parsed but not decoded, like the
@@ -242,6 +267,11 @@ cvec_status cvec_decode_indexed_dev(const cvec_dbatch_view *batch, const cvec_si
 cvec_status cvec_decode_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, void *d_out,
                             uint64_t *d_result, int32_t *d_status, void *d_workspace, size_t workspace_bytes,
                             void *stream);
+
+/* cvec_decode_dev / cvec_decode_indexed_dev with the options of this call (opts->d_gate must be NULL). */
+cvec_status cvec_decode_opt_dev(const cvec_dbatch_view *batch, const cvec_sink_chain *chain, const cvec_read_options *opts,
+                                void *d_out, uint64_t *d_result, int32_t *d_status, void *d_workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* ---- consumers of the per-section masks ----------------------------------------------------- */
 
@@ -386,6 +416,15 @@ cvec_status cvec_decode_batch(int32_t etype, const uint8_t *h_bytes, const uint6
 cvec_status cvec_encode_batch(int32_t etype, const void *h_values, const uint64_t *h_elem_off, uint64_t n_vectors,
                               uint8_t *h_bytes, size_t bytes_cap, uint64_t *h_byte_off /* n+1 */,
                               uint64_t *h_total_bytes);
+
+/* The two read calls with the options of this call (read path and tail rule; opts->d_gate and opts->indexed must be
+ * zero: the batch lives in host memory). */
+cvec_status cvec_filter_count_batch_opt(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off,
+                                        uint64_t n_vectors, const cvec_pred *pred, const cvec_read_options *opts,
+                                        uint64_t *h_total, uint64_t *h_per_vector /*nullable*/, int32_t *h_status /*nullable*/);
+cvec_status cvec_decode_batch_opt(int32_t etype, const uint8_t *h_bytes, const uint64_t *h_byte_off, uint64_t n_vectors,
+                                  const cvec_sink_chain *chain, const cvec_read_options *opts, void *h_out,
+                                  uint64_t out_cap_elems, uint64_t *h_out_off /*nullable*/, int32_t *h_status /*nullable*/);
 
 /* ---- appender handle: VectorAppender<T, W> (src/vector.rs:207-379) ------------------------------ */
 /* What the crate's VectorU32Appender / VectorU64Appender / VectorF32XorAppender do for one vector:

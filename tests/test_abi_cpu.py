@@ -122,3 +122,72 @@ def test_shipped_library_has_no_shift_count_in_the_last_vgpr_and_the_meant_occup
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "kernels" in r.stdout
+
+
+def test_read_options_hold_per_call_and_per_thread():
+    """cvec_read_options: two threads resolve different options at the same time while a third keeps changing the
+    process-wide defaults; every call sees its own fields, a CVEC_OPT_DEFAULT field sees one of the defaults, and a
+    NULL struct sees the defaults.  (No device is touched: cvec_read_options_effective only resolves.)"""
+    import ctypes as C
+    import threading
+    import compressed_vec_amd as cv
+    from compressed_vec_amd import _native as N
+    lib = cv.lib()
+    stop = threading.Event()
+    errors = []
+
+    def flip():
+        i = 0
+        while not stop.is_set():
+            lib.cvec_set_tail_rule(i & 1)
+            lib.cvec_set_read_path((i >> 1) % 3)
+            i += 1
+
+    def resolve(opts):
+        p, t = C.c_int32(-7), C.c_int32(-7)
+        rc = lib.cvec_read_options_effective(C.byref(opts) if opts is not None else None, C.byref(p), C.byref(t))
+        return rc, p.value, t.value
+
+    def worker(path, tail):
+        o = N.read_options(path, tail)
+        for _ in range(20000):
+            rc, p, t = resolve(o)
+            if rc != 0 or (path is not None and p != N._PATHS[path]) or (tail is not None and t != N._TAILS[tail]) \
+                    or p not in (0, 1, 2) or t not in (0, 1):
+                errors.append((path, tail, rc, p, t))
+                return
+
+    flipper = threading.Thread(target=flip)
+    flipper.start()
+    try:
+        ts = [threading.Thread(target=worker, args=a) for a in
+              [("slots", "reference"), ("vstream", "format"), (None, "reference"), ("auto", None)]]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        stop.set()
+        flipper.join()
+        lib.cvec_set_tail_rule(N.TAIL_FORMAT)
+        lib.cvec_set_read_path(N.PATH_AUTO)
+    assert not errors, errors[:3]
+    assert resolve(None) == (0, N.PATH_AUTO, N.TAIL_FORMAT)
+    lib.cvec_set_tail_rule(N.TAIL_REFERENCE)
+    assert resolve(None) == (0, N.PATH_AUTO, N.TAIL_REFERENCE)
+    assert resolve(N.read_options(None, "format")) == (0, N.PATH_AUTO, N.TAIL_FORMAT)
+    lib.cvec_set_tail_rule(N.TAIL_FORMAT)
+    bad = N.read_options()
+    bad.tail_rule = 5
+    assert resolve(bad)[0] == N.ERR_BAD_ARGUMENT
+    bad = N.read_options()
+    bad.read_path = -2
+    assert resolve(bad)[0] == N.ERR_BAD_ARGUMENT
+    # argument checks of the _opt entry points that need no device
+    o = N.read_options(None, None, indexed=True)
+    tot = C.c_uint64(0)
+    p = cv.make_pred(cv.U32, 3)
+    assert lib.cvec_filter_count_batch_opt(cv.U32, None, None, 0, C.byref(p), C.byref(o), C.byref(tot), None, None) == N.ERR_BAD_ARGUMENT
+    o = N.read_options()
+    o.d_gate = 4096
+    assert lib.cvec_decode_opt_dev(None, None, C.byref(o), None, None, None, None, 0, None) == N.ERR_BAD_ARGUMENT

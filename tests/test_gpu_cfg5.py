@@ -272,6 +272,73 @@ def test_reference_tail_rule_behind_a_gate_over_a_resident_index(cv, oracle, ref
     assert total_f >= total
 
 
+def test_tail_rule_per_call_and_from_two_threads(cv, oracle):
+    """cvec_read_options: the tail rule as an option of the call.  With the process-wide default on the format's rule,
+    calls that ask for the reference's rule equal the oracle's reference mode (decode, counts, masks; resident and
+    through the host entry points) and calls that do not equal its default mode; then two threads run passes over
+    the same resident blob at the same time, each with its own rule, stream and workspace, and each keeps getting
+    its own rule's results."""
+    import contextlib
+    import threading
+    import torch
+    from compressed_vec_amd import synth
+    vals, eo = synth.batch_values("f32_xor", 512, VEC_LEN)
+    blob, bo = oracle.batch_encode(F32, vals, eo)
+    dev = cv.EncodedBatch("f32", blob, bo).to_device()
+    p = float(vals[1])
+    want = {}
+    for rule in ("format", "reference"):
+        with (oracle.ref_tail_quirk() if rule == "reference" else contextlib.nullcontext()):
+            wtotal, wper, _, rc = oracle.batch_filter_count(F32, blob, bo, p)
+            assert rc == 0
+            sb = dev.d_sec_base.cpu().numpy().view(np.uint64) * np.uint64(256)
+            wdec, _, rc = oracle.batch_decode(F32, blob, bo, sb)
+            assert rc == 0
+            want[rule] = (wtotal, wper, _bits(wdec).copy(), _oracle_masks(oracle, blob, bo, p))
+    assert want["format"][0] != want["reference"][0] or not np.array_equal(want["format"][2], want["reference"][2])
+    for rule in ("reference", "format", "reference"):
+        total, per, st, masks = dev.filter_count(p, per_vector=True, return_status=True, return_masks=True, tail_rule=rule)
+        assert total == want[rule][0] and np.array_equal(per, want[rule][1]) and not st.any(), rule
+        assert np.array_equal(masks, want[rule][3]), rule
+        dec, _ = dev.decode(tail_rule=rule)
+        assert np.array_equal(_bits(dec), want[rule][2]), rule
+        host = cv.EncodedBatch("f32", blob, bo)
+        assert cv.filter_count_host(host, p, tail_rule=rule) == want[rule][0]
+        hdec, _ = cv.decode_host(host, tail_rule=rule)
+        assert np.array_equal(_bits(hdec), want[rule][2]), rule
+    # no option: the process-wide default, which is still the format's rule
+    assert dev.filter_count(p) == want["format"][0]
+    # a resident index keeps serving calls with either rule
+    idx = cv.EncodedBatch("f32", blob, bo).to_device().build_index()
+    for rule in ("reference", "format"):
+        assert idx.filter_count(p, tail_rule=rule) == want[rule][0]
+    errors = []
+
+    def worker(rule):
+        try:
+            view = cv.DeviceBatch(dev.etype, dev.d_bytes, dev.d_byte_off, dev.d_sec_base, dev.n_vectors, dev.n_sections,
+                                  dev.n_bytes)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                res = view.result_buffer()
+                for i in range(200):
+                    view.filter_count_async(p, result=res, tail_rule=rule)
+                    if i % 20 == 19:
+                        stream.synchronize()
+                        if int(res[0].item()) != want[rule][0]:
+                            errors.append((rule, i, int(res[0].item())))
+                            return
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((rule, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in ("format", "reference", "format", "reference")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_sparse_bench_vector_built_through_append_nulls(cv, oracle):
     """The reference's very sparse u32 vector exactly as benches/bench.rs:160-170 builds it:
     append_nulls(2475), 50 values, append_nulls(4950), the same 50 values, finish(10000).  The bytes
