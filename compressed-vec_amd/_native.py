@@ -181,6 +181,10 @@ SIGNATURES = {
                                       C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "cvec_encode_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.POINTER(C.c_uint64)]),
+    "cvec_allreduce_counts": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "cvec_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "cvec_comm_init_rank": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "cvec_comm_destroy": (C.c_int32, [C.c_void_p]),
     "cvec_debug_fail_chunk": (C.c_int32, [C.c_int64]),
 }
 

@@ -94,6 +94,7 @@ static cvec_status hip_fail(hipError_t e, const char *what) {
 namespace cvec {
 // for the other translation units: keeps the message that cvec_last_hip_error() returns
 cvec_status record_hip_error(hipError_t e, const char *what) { return hip_fail(e, what); }
+void record_message(const char *msg) { snprintf(g_hip_err, sizeof(g_hip_err), "%s", msg); }
 } // namespace cvec
 #define HIP_TRY(expr)                                   \
     do {                                                \

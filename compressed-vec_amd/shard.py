@@ -39,6 +39,48 @@ def allreduce_counts(counts):
     return counts
 
 
+class Communicator:
+    """An RCCL communicator made and used through the library's C entry points (cvec_comm_*, cvec_allreduce_counts):
+    what a host program without RCCL bindings of its own uses.  Rank 0 creates the id (Communicator.unique_id()) and
+    hands its 128 bytes to the other ranks by any means (a file, a socket, torch.distributed's broadcast); every rank
+    then constructs Communicator(id, n_ranks, rank) with its GPU current."""
+
+    def __init__(self, comm_id, n_ranks, rank):
+        import ctypes as C
+        from . import _native as N
+        assert len(comm_id) == 128
+        self._buf = C.create_string_buffer(bytes(comm_id), 128)
+        h = C.c_void_p()
+        N.check(N.lib().cvec_comm_init_rank(self._buf, int(n_ranks), int(rank), C.byref(h)))
+        self.handle, self.n_ranks, self.rank = h, int(n_ranks), int(rank)
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _native as N
+        buf = C.create_string_buffer(128)
+        N.check(N.lib().cvec_comm_unique_id(buf))
+        return buf.raw
+
+    def allreduce_counts(self, d_result, n_blocks=None):
+        """Reduces result blocks (int64 device tensor of 4 * n_blocks words) in place over the ranks, on the current
+        stream: totals and failed-vector counts are summed, the largest status takes the maximum."""
+        import ctypes as C
+        import torch
+        from . import _native as N
+        nb = d_result.numel() // N.RESULT_WORDS if n_blocks is None else int(n_blocks)
+        assert d_result.is_cuda and d_result.dtype == torch.int64 and d_result.is_contiguous() and nb * N.RESULT_WORDS <= d_result.numel()
+        N.check(N.lib().cvec_allreduce_counts(C.c_void_p(d_result.data_ptr()), nb, self.handle,
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return d_result
+
+    def close(self):
+        from . import _native as N
+        if self.handle is not None and self.handle.value:
+            N.check(N.lib().cvec_comm_destroy(self.handle))
+        self.handle = None
+
+
 class CountBucketRing:
     """Result blocks of consecutive query steps, all-reduced in buckets.
 

@@ -501,6 +501,25 @@ cvec_status cvec_series_appender_unseal(cvec_series_appender *a);
 cvec_status cvec_series_appender_stats(const cvec_series_appender *a, uint64_t *n_segments, uint64_t *encoded_bytes,
                                        uint64_t *state_bytes);
 
+/* ---- across GPUs: the all-reduce of result blocks -------------------------------------------------- */
+/* Vectors are independent (each rank filters its own shard; nothing of the data path crosses GPUs), so the only
+ * exchange of a sharded query is the sum of the ranks' result blocks: count_hits (src/filter.rs:296-299) over a
+ * batch that is spread over several GPUs.  d_result: n_blocks consecutive result blocks (CVEC_RESULT_WORDS u64 each)
+ * in device memory, reduced in place over the ranks of `comm`: word 0 (total) and word 1 (failed vectors) are
+ * summed, word 2 (largest status) takes the maximum, word 3 is summed.  `comm` is an RCCL communicator
+ * (ncclComm_t) that the caller owns - its own, or one from cvec_comm_init_rank; the collective is enqueued on
+ * `stream` like any _dev operation (one grouped launch for all blocks).  The library binds librccl at the first of
+ * these calls (the copy the process has loaded already, else the ROCm installation's; CVEC_RCCL_PATH overrides) and
+ * does not depend on it otherwise.  RCCL failures come back as CVEC_ERR_HIP with the text in cvec_last_hip_error(). */
+cvec_status cvec_allreduce_counts(uint64_t *d_result, uint32_t n_blocks, void *comm, void *stream);
+/* For callers without RCCL bindings of their own: ncclGetUniqueId (one rank calls it and hands the 128 bytes to the
+ * others by any means), ncclCommInitRank (every rank, with its device current; blocks until all ranks have joined)
+ * and ncclCommDestroy. */
+typedef struct cvec_comm_id { char bytes[128]; } cvec_comm_id;
+cvec_status cvec_comm_unique_id(cvec_comm_id *id);
+cvec_status cvec_comm_init_rank(const cvec_comm_id *id, int32_t n_ranks, int32_t rank, void **comm);
+cvec_status cvec_comm_destroy(void *comm);
+
 /* Test hook, no counterpart in the reference: makes the next *_batch call of the calling thread fail
  * with CVEC_ERR_HIP at chunk `chunk` (0-based) after that chunk's copies and kernels have been queued,
  * to exercise the error exit of the pipeline (which must wait for everything in flight before it
