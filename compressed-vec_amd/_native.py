@@ -136,6 +136,7 @@ SIGNATURES = {
     "cvec_appender_finish": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_uint64)]),
     "cvec_appender_reader": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "cvec_appender_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "cvec_series_appender_new": (C.c_int32, [C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]),
     "cvec_series_appender_free": (None, [C.c_void_p]),
     "cvec_series_appender_reset": (C.c_int32, [C.c_void_p]),

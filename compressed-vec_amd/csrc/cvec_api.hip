@@ -391,12 +391,19 @@ const char *cvec_status_name(cvec_status s) {
     }
 }
 
-// The current device's copy of `scratch` (looked up on the first use on that device).
-static cvec_status static_scratch(void **out) {
+// The current device's copy of `scratch`.  `resolve`: look the address up if this device has none yet (cvec_init);
+// the entry point that must not allocate only reads what cvec_init stored, because the first symbol lookup on a
+// device may load the code object there, which allocates and is not allowed under stream capture.
+static cvec_status static_scratch(void **out, bool resolve) {
     int d = -1;
     HIP_TRY(hipGetDevice(&d));
     if (d < 0 || d >= MAX_STATIC_DEVICES) return CVEC_ERR_BAD_ARGUMENT;
     void *p = g_static_scratch[d].load(std::memory_order_acquire);
+    if (!p && !resolve) {
+        snprintf(g_hip_err, sizeof(g_hip_err), "cvec_filter_count_static_dev: call cvec_init(%d) first (it resolves the "
+                                               "static scratch of the device; this entry point itself allocates and loads nothing)", d);
+        return CVEC_ERR_BAD_ARGUMENT;
+    }
     if (!p) {
         HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p) return hip_fail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch)");
@@ -414,7 +421,7 @@ cvec_status cvec_init(int device) {
     HIP_TRY(hipSetDevice(device));
     (void)hipFree(nullptr);
     void *p = nullptr;
-    return static_scratch(&p); // this device's address of the static scratch, so that no later call has to look it up
+    return static_scratch(&p, true); // this device's address of the static scratch: the entry point that uses it only reads it
 }
 
 cvec_status cvec_set_read_path(int32_t path) {
@@ -598,7 +605,7 @@ cvec_status cvec_filter_count_static_dev(const cvec_dbatch_view *batch, const cv
         return CVEC_ERR_WORKSPACE;
     }
     void *ws = nullptr;
-    cvec_status st = static_scratch(&ws);
+    cvec_status st = static_scratch(&ws, false);
     if (st) return st;
     // Every slot of the scratch that the kernels read is written earlier in the same call (descriptors,
     // per-section results, per-vector header statuses, the index tag), so nothing has to be cleared.

@@ -604,6 +604,15 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
     DeviceScope scope(a->device);
     hipStream_t st = (hipStream_t)stream;
     const uint64_t n = a->n;
+    // The closing segments belong to a seal that succeeded: every other way out of this call drops them, so that a
+    // later seal never gathers segments of an attempt that failed half-way (their arena space comes back with the
+    // next finish() or reset()).
+    a->tail.clear();
+    struct TailGuard {
+        cvec_series_appender *a;
+        bool keep;
+        ~TailGuard() { if (!keep) a->tail.clear(); }
+    } tail_guard{a, false};
     if (!reader) {
         // src/vector.rs:344-349: more values than rows, or more rows than the header's u32 can say
         unsigned long long max_len = 0;
@@ -644,7 +653,7 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
                 a->tail.push_back(t);
             }
             cvec_status cs = null_run_segment(a, &a->tail, st);
-            if (cs) { a->tail.clear(); return cs; }
+            if (cs) return cs;
         }
     }
     // pointer tables of the segments, then sizes -> offsets
@@ -678,6 +687,7 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
         SER_TRY(hipMemsetAsync(a->out_sec.p, 0, 8, st));
         SER_TRY(hipStreamSynchronize(st));
     }
+    tail_guard.keep = true;
     a->sealed = reader ? 2 : 1;
     a->sealed_rows = total_num_rows;
     a->sealed_bytes = tot[0];

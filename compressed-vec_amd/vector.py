@@ -56,6 +56,12 @@ class VectorAppender:
     def append_nulls(self, num_nulls):
         N.check(N.lib().cvec_appender_append_nulls(self._h, int(num_nulls)))
 
+    def stats(self):
+        """(bytes of the sections encoded so far, bytes of values the handle still holds raw)."""
+        e, r = C.c_uint64(0), C.c_uint64(0)
+        N.check(N.lib().cvec_appender_stats(self._h, C.byref(e), C.byref(r)))
+        return e.value, r.value
+
     def _bytes_of(self, call):
         """Runs a finish / reader call twice: once to learn the size, once into a buffer of that size."""
         need = C.c_size_t(0)

@@ -209,7 +209,9 @@ cvec_status cvec_filter_count_set_dev(const cvec_dbatch_view *batch, const uint6
  * cvec_workspace_bytes(n_vectors, n_sections) exceeds CVEC_STATIC_SCRATCH_BYTES (about 170 000
  * sections) is rejected with CVEC_ERR_WORKSPACE and a message in cvec_last_hip_error().  All calls on
  * one GPU share that GPU's scratch: calls that overlap in time on one GPU (two streams, two threads)
- * race and must be serialised by the caller.  Results are identical to cvec_filter_count_dev's. */
+ * race and must be serialised by the caller.  cvec_init(device) must have run for the device (it resolves the
+ * address of that GPU's scratch; CVEC_ERR_BAD_ARGUMENT otherwise), so that the call itself touches no loader or
+ * allocator and can be recorded by hipStreamBeginCapture.  Results are identical to cvec_filter_count_dev's. */
 #define CVEC_STATIC_SCRATCH_BYTES (2 * 1024 * 1024)
 cvec_status cvec_filter_count_static_dev(const cvec_dbatch_view *batch, const cvec_pred *pred, uint64_t *d_result,
                                          uint64_t *d_per_vector, int32_t *d_status, uint8_t *d_masks, void *stream);
@@ -428,12 +430,15 @@ cvec_status cvec_decode_batch_opt(int32_t etype, const uint8_t *h_bytes, const u
 
 /* ---- appender handle: VectorAppender<T, W> (src/vector.rs:207-379) ------------------------------ */
 /* What the crate's VectorU32Appender / VectorU64Appender / VectorF32XorAppender do for one vector:
- * values and nulls are appended, finish() returns the vector's bytes.  The handle keeps the open
- * section, the values of the complete sections and the runs of explicit null sections (as counts:
- * append_nulls(n) costs no memory per null section) on the host, one vector being far below GPU launch
- * granularity; finish() and reader() encode the value sections on the GPU and write the null-section
- * count into the header (num_null_sections, src/vector.rs:160-169, :321-327).  Not thread-safe: one
- * handle per thread, like the reference's &mut self. */
+ * values and nulls are appended, finish() returns the vector's bytes.  The handle lives on the host, one vector
+ * being far below GPU launch granularity, and like the reference's appender (a section is encoded when it fills,
+ * src/vector.rs:270-281) it holds encoded sections, not the values that went into them: complete sections wait as
+ * raw values until 1024 of them have gathered, then that run is encoded on the GPU in one call and only its bytes
+ * stay.  Beside them the handle keeps the open section (the reference's write_buf) and the runs of explicit null
+ * sections as counts (append_nulls(n) costs no memory per null section); finish() and reader() encode what is
+ * still raw and write the null-section count into the header (num_null_sections, src/vector.rs:160-169, :321-327).
+ * If the encoder is not available when a run is due (no device), the run stays raw and append still succeeds; the
+ * error surfaces in finish() / reader().  Not thread-safe: one handle per thread, like the reference's &mut self. */
 typedef struct cvec_appender cvec_appender;
 /* try_new (src/vector.rs:223-234): initial_capacity < 8 is CVEC_NOT_ENOUGH_SPACE, as the header write
  * into a buffer that small fails in the reference. */
@@ -454,6 +459,9 @@ cvec_status cvec_appender_finish(cvec_appender *a, uint64_t total_num_rows, uint
 /* reader (src/vector.rs:372-378): the bytes of the vector as written so far, i.e. its complete
  * sections; values in the open section are not visible yet.  Same out / cap / len rules as finish. */
 cvec_status cvec_appender_reader(cvec_appender *a, uint8_t *out, size_t cap, size_t *len);
+/* Host memory the handle holds for the vector: bytes of the sections encoded so far, and bytes of values that are
+ * still raw (complete sections waiting for their run, and the open section). */
+cvec_status cvec_appender_stats(const cvec_appender *a, uint64_t *encoded_bytes, uint64_t *raw_value_bytes);
 
 /* ---- series appender: one VectorAppender<T, W> per series, all of them resident on the device ------- */
 /* What n_series appenders of the crate (src/vector.rs:207-379) do when they are driven side by side, as a

@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libcvec_oracle.so")
+# CVEC_ORACLE_LIB: another build of the same source (the sanitizer build, `make -C oracle sanitize`) instead
+_LIB_OVERRIDE = os.environ.get("CVEC_ORACLE_LIB")
+_LIB_PATH = _LIB_OVERRIDE or os.path.join(_HERE, "libcvec_oracle.so")
 
 OK, NOT_ENOUGH_SPACE, INPUT_TOO_SHORT, BAD_OFFSET, INVALID_SECTION_TYPE, INVALID_FORMAT, \
     INVALID_NUM_ROWS, WRONG_VECTOR_TYPE, SCROLL_ERR = range(9)
@@ -24,6 +26,8 @@ NP_DTYPE = {U64: np.uint64, U32: np.uint32, F32: np.float32}
 def build(force=False):
     """Compile the oracle with gcc (a few hundred ms)."""
     src = os.path.join(_HERE, "cvec_oracle.c")
+    if _LIB_OVERRIDE:
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libcvec_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

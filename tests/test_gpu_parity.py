@@ -392,6 +392,43 @@ def test_appender_long_null_runs_are_counts(cv, oracle):
     assert len(got) < 10_000_000 and got == bytes(want)
 
 
+def test_appender_holds_encoded_sections_not_values(cv, oracle):
+    """The handle's memory behaves like the reference appender's (src/vector.rs:270-281: a section is encoded when
+    it fills): after far more than a run of 1024 sections the handle holds encoded bytes and less than one run of raw
+    values; the bytes - runs encoded at different times, null runs between them, readers in between - equal the
+    oracle's appender driven the same way, for every element type."""
+    rng = np.random.default_rng(404)
+    for tname, et in (("u32", oracle.U32), ("u64", oracle.U64), ("f32", oracle.F32)):
+        a = {"u32": cv.VectorU32Appender, "u64": cv.VectorU64Appender, "f32": cv.VectorF32XorAppender}[tname].try_new(8192)
+        o = oracle.Appender(et, 8192)
+        w = 8 if tname == "u64" else 4
+        total = 0
+        for step in range(9):
+            n = int(rng.integers(60_000, 140_000))
+            if tname == "f32":
+                x = (rng.integers(0, 1 << 12, size=n) / 1.4).astype(np.float32)
+            else:
+                x = rng.integers(0, 1 << int(rng.integers(3, 30)), size=n).astype(NPD[tname])
+            for app in (a, o):
+                app.append_many(x)
+            total += n
+            if step % 3 == 1:
+                k = int(rng.integers(1, 3000))
+                for app in (a, o):
+                    app.append_nulls(k)
+                total += k
+            if step % 4 == 2:
+                r = a.reader()
+                assert r.num_elements() == total - total % 256
+            enc, raw = a.stats()
+            assert raw < (1024 + 1) * 256 * w, (tname, step, raw)
+        enc, raw = a.stats()
+        assert enc > 0 and total > 2 * 1024 * 256                   # at least two runs were encoded on the way
+        got, want = a.finish(total + 777), o.finish(total + 777)
+        assert got == bytes(want), tname
+        assert a.stats() == (0, 0)
+
+
 def test_null_section_through_addconst_keeps_base_bits(cv, oracle):
     # src/sink.rs:314-317
     enc = cv.VectorF32XorAppender.try_new(64).encode_all(np.zeros(300, dtype=np.float32))
