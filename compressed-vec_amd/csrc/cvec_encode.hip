@@ -287,15 +287,17 @@ struct RunMeta {
     uint64_t e0;    // first element of the section in `values`
     uint32_t valid; // elements that exist (the rest of the section is zero padding); 0 = no section
     uint32_t avail; // elements of the value array from e0 on, at most one section
+    uint32_t vec;   // the vector the section belongs to
 };
 
 __device__ inline RunMeta run_meta(const uint64_t *__restrict__ elem_off, const uint64_t *__restrict__ sec_base,
                                    const uint32_t *__restrict__ sec_vec, uint64_t n_vectors, uint64_t slot, bool active) {
     RunMeta m;
-    m.e0 = 0; m.valid = 0; m.avail = 0;
+    m.e0 = 0; m.valid = 0; m.avail = 0; m.vec = 0;
     const uint64_t n_slots = sec_base[n_vectors], n_values = elem_off[n_vectors];
     if (active && slot < n_slots) {
         const uint32_t v = sec_vec[slot];
+        m.vec = v;
         const uint64_t k = slot - sec_base[v];
         m.e0 = elem_off[v] + k * FIXED_LEN;
         const uint64_t left = elem_off[v + 1] - m.e0;
@@ -522,6 +524,213 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = xn[i];
+    }
+}
+
+// ---- one pass: sizes, offsets and bytes of a tile of sections in one kernel -----------------------------------------
+// The two passes above read every value twice, because a section's place in the blob depends on the sizes of all
+// sections before it.  Here a workgroup owns a tile of consecutive section slots and reads its values once:
+//   1. every wave loads its share of the tile's sections, plans and transforms them, computes their sizes and parks
+//      the transformed values in LDS (a section is 1 or 2 KiB there; kind, base and size stay in the lane that has
+//      the section's number);
+//   2. the tile's total goes into the tile's state word (flag | value in one 64-bit store), and the first wave looks
+//      back over the state words of the tiles in front of it: it adds up their totals until it meets a tile whose
+//      offset is already known, then publishes its own (decoupled look-back; tiles take their numbers from a counter,
+//      so every tile in front of a running tile is running or done and the wait always ends);
+//   3. every wave builds the bytes of its sections from the parked values and copies them out.
+// The scan of the section sizes falls out of the same pass (sec_scan, which the header kernel needs).
+//
+// Built with -DCVEC_ENC_ONE_PASS only.  It is bit-exact (the whole GPU suite passes on it) and moves a third less
+// memory, and it is slower than the two passes: 0.98 ms against 0.19 + 0.45 ms per GiB of incompressible f32, 0.85
+// against 0.18 + 0.30 ms on dense u32.  The work on a section is a chain of dependent cross-lane steps (the min / max
+// reduction, the octet scan, the ORs into the image) that takes a wave about 1.5 us whatever else the CU does, so the
+// section rate is set by the number of resident waves: the two kernels run 32 waves per CU, this one 16, because it
+// holds the state of both passes in registers (88 to 99 VGPRs: one workgroup of 16 waves per CU) next to 64 KiB of
+// parked values.  Forced to 64 VGPRs it spills and takes 1.29 ms; with 4 waves per workgroup (two workgroups per
+// CU) 1.0 ms.  The look-back itself costs little (the kernel without it, with garbage offsets, takes as long).
+// A tile is 64 KiB of values (64 sections of 32-bit elements, 32 of 64-bit ones) in the hands of 16 waves: the
+// section work is chains of dependent cross-lane operations, which need many waves per SIMD to fill the issue slots
+// (two workgroups of 16 waves per CU = 8 per SIMD; with 4 waves per workgroup the same kernel ran 40 % slower than
+// the two passes it replaces).
+constexpr int ENC_TILE_THREADS = 1024;
+template <int W> struct EncTile {
+    static constexpr int WAVES = ENC_TILE_THREADS / 64;
+    static constexpr int PER_WAVE = W == 4 ? 4 : 2;
+    static constexpr int SECTIONS = WAVES * PER_WAVE;
+};
+constexpr uint64_t TILE_FLAG_TOTAL = 1ull << 62, TILE_FLAG_OFFSET = 2ull << 62, TILE_VALUE = (1ull << 62) - 1;
+
+__device__ inline uint64_t wave_sum_u64(uint64_t x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+template <int ETYPE>
+__global__ __launch_bounds__(ENC_TILE_THREADS) void k_enc_tile(const typename EncT<ETYPE>::U *__restrict__ values,
+                                                           const uint64_t *__restrict__ elem_off,
+                                                           const uint64_t *__restrict__ sec_base, uint64_t n_vectors,
+                                                           const uint32_t *__restrict__ sec_vec, uint64_t max_slots,
+                                                           uint32_t n_tiles, uint64_t *__restrict__ tile_state,
+                                                           uint32_t *__restrict__ ticket, uint64_t *__restrict__ sec_scan,
+                                                           uint8_t *__restrict__ bytes) {
+    using U = typename EncT<ETYPE>::U;
+    constexpr int W = EncT<ETYPE>::W;
+    constexpr int PER_WAVE = EncTile<W>::PER_WAVE, WAVES = EncTile<W>::WAVES;
+    typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
+    // a slot per section: first the parked values (1 or 2 KiB), later, in the same place, the image of its bytes
+    static_assert(EncBuf<W>::DWORDS * 4 >= FIXED_LEN * W, "a slot holds a section's values");
+    __shared__ __attribute__((aligned(16))) uint32_t s_slot[WAVES][PER_WAVE][EncBuf<W>::DWORDS];
+    // what the waves tell each other, in two copies: a wave can be one barrier ahead of another
+    __shared__ uint64_t s_wave_total[2][WAVES];
+    __shared__ uint64_t s_tile_base[2];
+    __shared__ uint32_t s_next[2];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // The persistent workgroup takes its tiles from a counter, the next one while it works on the current one, and
+    // has the next tile's values in flight (in registers) while it waits for its offset and writes the current
+    // tile's bytes: a workgroup holds 64 KiB of LDS, so a CU runs two of them and every wave has to keep many
+    // loads in flight.
+    U x[PER_WAVE][4];
+    RunMeta m;
+    auto fetch = [&](uint32_t tile) {
+        const uint64_t slot = ((uint64_t)tile * WAVES + wave) * PER_WAVE + lane;
+        m = run_meta(elem_off, sec_base, sec_vec, n_vectors, slot, tile < n_tiles && lane < PER_WAVE && slot < max_slots);
+#pragma unroll
+        for (int r = 0; r < PER_WAVE; r++)
+            load_section<ETYPE>(values, lane_val(m.e0, r), lane_val(m.valid, r), lane_val(m.avail, r), lane, x[r]);
+    };
+    if (threadIdx.x == 0) s_next[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    uint32_t tile = s_next[0];
+    fetch(tile);
+    for (int it = 0; tile < n_tiles; it ^= 1) {
+        if (threadIdx.x == 0) s_next[it ^ 1] = atomicAdd(ticket, 1u);
+        const uint64_t slot = ((uint64_t)tile * WAVES + wave) * PER_WAVE + lane;
+        const int cnt = __popcll(__ballot(m.valid != 0));
+        const uint32_t my_vec = m.vec;
+        // ---- 1: sizes; the transformed values go to LDS, what else the emit needs stays in lane r ---------------------
+        uint32_t my_size = 0, my_kind = K_NULL;
+        U my_min = 0, my_max = 0, my_first = 0;
+#pragma unroll
+        for (int r = 0; r < PER_WAVE; r++) {
+            if (r < cnt) {
+                const SecPlan<U> p = plan_section<ETYPE>(x[r], lane);
+                uint32_t size;
+                if (p.kind == K_NULL) size = 1;
+                else if (p.kind == K_CONST) size = 1 + W;
+                else {
+                    transform_section<ETYPE>(x[r], p.kind, p.minv, lane);
+                    size = (p.kind == K_DELTA ? DELTA_HDR : 3) + pair_scan_total(octet_info<U>(x[r], lane).size).total;
+                    u32x4 *dst = (u32x4 *)s_slot[wave][r];
+                    if constexpr (W == 4) {
+                        dst[lane] = u32x4{x[r][0], x[r][1], x[r][2], x[r][3]};
+                    } else {
+                        dst[lane] = u32x4{(uint32_t)x[r][0], (uint32_t)(x[r][0] >> 32), (uint32_t)x[r][1], (uint32_t)(x[r][1] >> 32)};
+                        dst[64 + lane] = u32x4{(uint32_t)x[r][2], (uint32_t)(x[r][2] >> 32), (uint32_t)x[r][3], (uint32_t)(x[r][3] >> 32)};
+                    }
+                }
+                if (lane == r) { my_size = size; my_kind = p.kind; my_min = p.minv; my_max = p.maxv; my_first = p.first; }
+            }
+        }
+        // ---- 2: the tile's place in the blob --------------------------------------------------------------------------
+        // (offsets count section bytes only; the 16-byte vector headers are added by vector number)
+        uint64_t incl = my_size; // inclusive scan over the wave's lanes (sizes sit in lanes 0 .. PER_WAVE - 1, zeros above)
+#pragma unroll
+        for (int d = 1; d < PER_WAVE; d <<= 1) {
+            const uint64_t y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        if (lane == PER_WAVE - 1) s_wave_total[it][wave] = incl;
+        __syncthreads();
+        // the next tile's values: requested now, used in the next pass of the loop
+        const uint32_t next = s_next[it ^ 1];
+        fetch(next);
+        if (wave == 0) {
+            uint64_t tile_total = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) tile_total += s_wave_total[it][w];
+            uint64_t before = 0;
+            if (tile == 0) {
+                if (lane == 0) __hip_atomic_store(&tile_state[0], TILE_FLAG_OFFSET | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0) __hip_atomic_store(&tile_state[tile], TILE_FLAG_TOTAL | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // lane l looks at the l-th tile in front of the window's start; the virtual tile in front of tile 0 has offset 0
+                int64_t at = (int64_t)tile - 1;
+                for (;;) {
+                    const int64_t t = at - lane;
+                    const uint64_t st = t >= 0 ? __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : TILE_FLAG_OFFSET;
+                    const unsigned long long known = __ballot((st >> 62) == 2), blank = __ballot((st >> 62) == 0);
+                    const int first_known = known ? (int)__builtin_ctzll(known) : 64;
+                    // every tile nearer than the first one with a known offset has to have its total out
+                    const unsigned long long nearer = first_known >= 64 ? ~0ull : ((1ull << first_known) - 1ull);
+                    if (blank & nearer) { __builtin_amdgcn_s_sleep(2); continue; }
+                    const uint64_t take = lane <= first_known ? (st & TILE_VALUE) : 0ull;
+                    before += wave_sum_u64(take);
+                    if (first_known < 64) break;
+                    at -= 64;
+                }
+                if (lane == 0) __hip_atomic_store(&tile_state[tile], TILE_FLAG_OFFSET | (before + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) s_tile_base[it] = before;
+        }
+        __syncthreads();
+        uint64_t my_off = s_tile_base[it] + incl - my_size;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) my_off += w < wave ? s_wave_total[it][w] : 0ull;
+        if (lane < PER_WAVE && slot < max_slots) {
+            sec_scan[slot] = my_off;
+            if (slot == max_slots - 1) sec_scan[max_slots] = my_off + my_size;
+        }
+        const uint64_t my_dst = HEADER_BYTES * ((uint64_t)my_vec + 1) + my_off;
+        // ---- 3: bytes -------------------------------------------------------------------------------------------------
+        for (int r = 0; r < cnt; r++) {
+            const uint64_t dst_off = lane_val(my_dst, r);
+            const uint32_t size = lane_val(my_size, r), kind = lane_val(my_kind, r);
+            uint8_t *dst = bytes + dst_off;
+            if (kind == K_NULL) { // NullFixedSect::write (src/section.rs:440-443)
+                if (lane == 0) dst[0] = (uint8_t)K_NULL;
+            } else if (kind == K_CONST) { // ConstFixedSect::write (src/section.rs:795-803): values[0], not min
+                const U first = lane_val(my_first, r);
+                if (lane == 0) {
+                    dst[0] = (uint8_t)K_CONST;
+                    if constexpr (W == 4) *(u32u *)(dst + 1) = first; else *(u64u *)(dst + 1) = first;
+                }
+            } else {
+                const U minv = lane_val(my_min, r), maxv = lane_val(my_max, r);
+                U y[4];
+                uint32_t *buf = s_slot[wave][r];
+                const u32x4 *src = (const u32x4 *)buf;
+                if constexpr (W == 4) {
+                    const u32x4 v = src[lane];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) y[i] = v[i];
+                } else {
+                    const u32x4 a = src[lane], b = src[64 + lane];
+                    y[0] = (uint64_t)a[0] | ((uint64_t)a[1] << 32); y[1] = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+                    y[2] = (uint64_t)b[0] | ((uint64_t)b[1] << 32); y[3] = (uint64_t)b[2] | ((uint64_t)b[3] << 32);
+                }
+                // (the values are in registers now: LDS serves a wave in order, so the zeroes below land behind the reads)
+                const uint32_t phase = (uint32_t)(dst_off & 15);
+                uint8_t *bufb = (uint8_t *)buf + phase;
+                const uint32_t npieces = (phase + size + 15) >> 4;
+                for (uint32_t d = lane; d < npieces; d += 64) ((uint4 *)buf)[d] = make_uint4(0, 0, 0, 0);
+                const uint32_t hdr = kind == K_DELTA ? DELTA_HDR : 3;
+                if (lane == 0) {
+                    bufb[0] = (uint8_t)kind;
+                    const uint32_t len16 = kind == K_XOR ? size : size - hdr; // src/section.rs:579-581, :659-661, :745-748
+                    bufb[1] = (uint8_t)len16; bufb[2] = (uint8_t)(len16 >> 8);
+                    if (kind == K_DELTA) {
+                        bufb[3] = (uint8_t)bitlen_u((U)(maxv - minv));                    // src/section.rs:663
+                        for (int i = 0; i < W; i++) bufb[4 + i] = (uint8_t)(minv >> (8 * i)); // base; bytes 4+W..11 stay 0
+                    }
+                }
+                image_octets<U>(y, lane, buf, phase, hdr, 32);
+                image_copy_out(buf, phase, size, dst, lane);
+            }
+        }
+        tile = next;
     }
 }
 
@@ -859,6 +1068,8 @@ struct EncWs {
     uint64_t *sec_size;
     uint64_t *sec_scan;
     uint64_t *scan_scratch;
+    uint64_t *tile_state; // one-pass kernel: a state word per tile, and behind them the counter that numbers the tiles
+    size_t tile_bytes;
     size_t total;
 };
 static inline size_t al(size_t x) { return (x + 255) / 256 * 256; }
@@ -872,6 +1083,8 @@ static EncWs carve_enc_ws(void *base, uint64_t n_vectors, uint64_t n_el) {
     w.sec_scan = (uint64_t *)(b + off); off += al((max_slots + 2) * 8);
     const uint64_t m = max_slots > n_vectors ? max_slots : n_vectors;
     w.scan_scratch = (uint64_t *)(b + off); off += al(scan_scratch_words(m) * 8);
+    w.tile_bytes = al((max_slots / EncTile<8>::SECTIONS + 2) * 8 + 8);
+    w.tile_state = (uint64_t *)(b + off); off += w.tile_bytes;
     w.total = off;
     return w;
 }
@@ -893,6 +1106,20 @@ static void launch_encode_t(const void *d_values, const uint64_t *d_elem_off, ui
         run = run < 1 ? 1 : run > (uint32_t)ENC_MAX_RUN ? (uint32_t)ENC_MAX_RUN : run;
         const uint64_t waves = (max_slots + run - 1) / run;
         const uint32_t sblocks = (uint32_t)((waves + ENC_THREADS / 64 - 1) / (ENC_THREADS / 64));
+#ifdef CVEC_ENC_ONE_PASS
+        // one pass over the values (k_enc_tile; measured slower than the two passes, see its comment): the state words
+        // and the tile counter start at zero
+        constexpr int TS = EncTile<EncT<ETYPE>::W>::SECTIONS;
+        const uint32_t n_tiles = (uint32_t)((max_slots + TS - 1) / TS);
+        (void)hipMemsetAsync(w.tile_state, 0, w.tile_bytes, stream);
+        uint32_t *ticket = (uint32_t *)((uint8_t *)w.tile_state + w.tile_bytes - 8);
+        const uint32_t tgrid = n_tiles < 512u ? n_tiles : 512u; // two workgroups per CU (their LDS)
+        k_enc_tile<ETYPE><<<tgrid, ENC_TILE_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
+                                                             max_slots, n_tiles, w.tile_state, ticket, w.sec_scan, d_bytes);
+        k_enc_headers<<<vblocks, 256, 0, stream>>>(ETYPE, d_elem_off, d_sec_base, w.sec_scan, n, d_bytes, d_byte_off,
+                                                   d_result);
+        (void)run; (void)sblocks;
+#else
         k_enc_sizes<ETYPE><<<sblocks, ENC_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
                                                                 max_slots, run, w.sec_size);
         (void)launch_exclusive_scan(w.sec_size, max_slots, w.sec_scan, w.scan_scratch, stream);
@@ -900,6 +1127,7 @@ static void launch_encode_t(const void *d_values, const uint64_t *d_elem_off, ui
                                                    d_result);
         k_enc_emit<ETYPE><<<sblocks, ENC_THREADS, 0, stream>>>((const U *)d_values, d_elem_off, d_sec_base, n, w.sec_vec,
                                                                max_slots, run, w.sec_scan, d_bytes);
+#endif
     } else {
         (void)hipMemsetAsync(w.sec_scan, 0, 16, stream);
         k_enc_headers<<<vblocks, 256, 0, stream>>>(ETYPE, d_elem_off, d_sec_base, w.sec_scan, n, d_bytes, d_byte_off,

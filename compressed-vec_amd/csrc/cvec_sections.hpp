@@ -185,12 +185,16 @@ __device__ __forceinline__ out_rsrc_t chunk_out_rsrc(void *out_, uint64_t slot, 
 // is cleared for the extraction (the walk still uses the real one), which also leaves an Xor section's state as
 // the crate's XorSink leaves it (src/sink.rs:271-275).  `tail_from` = the first LDS address from which an octet
 // start is within 33 bytes of the vector's end (beyond every address for sections that end further away).
-template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0>
+struct NoPreStore { __device__ __forceinline__ void operator()() const {} };
+// `pre_store` (MODE_DECODE) runs once, in front of the chunk's first burst of output stores: the caller waits there
+// for whatever loads it has in flight.  A wait for loads behind a store has to drain the store as well (one counter
+// for both, no order between the two kinds), and a drained store is a full write round trip.
+template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0, class PreStore = NoPreStore>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
                                               uint32_t &mask_hi, out_rsrc_t orsrc, uint32_t ooff_in,
-                                              int32_t tail_from = 0x7fffffff) {
+                                              int32_t tail_from = 0x7fffffff, PreStore pre_store = PreStore()) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
     const uint32_t q = lane & 3;
@@ -387,6 +391,7 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             hold[2 * (k % HOLD)] = x0;
             hold[2 * (k % HOLD) + 1] = x1;
             if (k % HOLD == HOLD - 1) {
+                if (k == HOLD - 1) pre_store();
 #pragma unroll
                 for (int j = 0; j < HOLD; j++) {
                     const U y0 = hold[2 * j], y1 = hold[2 * j + 1];
