@@ -567,17 +567,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
 #endif
             // (region offset -> LDS address; sections that end far from the vector's end keep "never")
             const int32_t tail_from = TAILREF != 0 && cur.tail_from != 0x7fffffff ? (int32_t)lds_base + cur.tail_from : 0x7fffffff;
-            // decode: the next chunk's bytes are waited for in front of this chunk's first output stores (they were
-            // requested a few octets ago), not behind its last ones at the top of the loop
-            auto staged = [&]() {
-#ifndef CVEC_NO_PRESTORE
-#pragma unroll
-                for (int i = 0; i < PIECES; i++) asm volatile("" ::"v"(R[i]));
-                asm volatile("" ::"v"(d_next));
-#endif
-            };
             const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF>(
-                data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from, staged);
+                data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from);
             if constexpr (W == 4) {
                 const unsigned long long odd_m = __ballot(odd); // a lane only sees the octets that store its own elements
                 if (odd_m != 0) {
@@ -790,10 +781,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         // mode needs more registers than three workgroups per CU leave)
         const bool count_only = mode != MODE_DECODE && (d_masks == nullptr || bits_ok);
         bool small = count_only && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL);
-#ifdef CVEC_DECODE_SMALL
-        // experiment: decode passes of batches with small sections on the 12 KiB shape (three workgroups per CU)
-        if (mode == MODE_DECODE && n_bytes != 0 && (n_bytes / ns) * TILE + 2 * 16 <= region_span(REGION_PIECES_SMALL)) small = true;
-#endif
+        // (decode passes were measured on the 12 KiB shape as well: 3 to 6 % slower, like the 6 KiB one)
         // A third shape, 6 KiB regions at four workgroups per CU, for count-only passes over batches whose sections
         // average at most 378 bytes (dense integers, deltas): dense u32 0.202 -> 0.190 ms per GiB, u64 delta 0.171 ->
         // 0.169.  (Decode passes were measured on it too and lose 3 to 6 %: more waves interleave more partial-line
@@ -804,7 +792,6 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 3) tiny = count_only;
         if (shape_env == 4) tiny = false;
         if (tiny) small = false;
-        if (tail != nullptr) small = tiny = false; // the reference's tail rule is compiled for the large shape only
         const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
         uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
 #ifdef CVEC_PROBES
@@ -850,23 +837,22 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         uint32_t bucket = 1;
         while (bucket < pb.count) bucket *= 2;
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
-#ifdef CVEC_DECODE_SMALL
-#define CVEC_DECODE_SMALL_ON 1
-#else
-#define CVEC_DECODE_SMALL_ON 0
-#endif
 #define CVEC_LAUNCH_SEC_P(M, N, P, T)                                                                               \
     k_sections<ETYPE, M, N, P, T><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
                                                                    tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached, tail)
+#define CVEC_LAUNCH_SEC_T(M, N, T)                                                                                  \
+    do {                                                                                                            \
+        if ((M == MODE_FILTER || mode_bit_compare(M)) && tiny)                                                      \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || mode_bit_compare(M)) ? REGION_PIECES_TINY : REGION_PIECES), T); \
+        else if ((M == MODE_FILTER || mode_bit_compare(M)) && small)                                                \
+            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || mode_bit_compare(M)) ? REGION_PIECES_SMALL : REGION_PIECES), T); \
+        else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, T);                                                             \
+    } while (0)
 #define CVEC_LAUNCH_SEC(M, N)                                                                                       \
     do {                                                                                                            \
         /* (the conditional constants keep the shapes a mode never takes from being instantiated) */                \
-        if (tail != nullptr) CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, 1); /* the reference's tail rule: the large shape only */ \
-        else if ((M == MODE_FILTER || mode_bit_compare(M)) && tiny)                                                 \
-            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || mode_bit_compare(M)) ? REGION_PIECES_TINY : REGION_PIECES), 0); \
-        else if ((M == MODE_FILTER || mode_bit_compare(M) || (CVEC_DECODE_SMALL_ON && M == MODE_DECODE)) && small)   \
-            CVEC_LAUNCH_SEC_P(M, N, ((M == MODE_FILTER || mode_bit_compare(M) || (CVEC_DECODE_SMALL_ON && M == MODE_DECODE)) ? REGION_PIECES_SMALL : REGION_PIECES), 0); \
-        else CVEC_LAUNCH_SEC_P(M, N, REGION_PIECES, 0);                                                             \
+        if (tail != nullptr) CVEC_LAUNCH_SEC_T(M, N, 1); /* the reference's tail rule */                            \
+        else CVEC_LAUNCH_SEC_T(M, N, 0);                                                                            \
     } while (0)
 #define CVEC_LAUNCH_BUCKET(M)                                                                                       \
     switch (bucket) {                                                                                               \
@@ -895,6 +881,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         }
 #undef CVEC_LAUNCH_BUCKET
 #undef CVEC_LAUNCH_SEC
+#undef CVEC_LAUNCH_SEC_T
 #undef CVEC_LAUNCH_SEC_P
     }
 }

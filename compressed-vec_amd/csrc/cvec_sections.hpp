@@ -185,16 +185,12 @@ __device__ __forceinline__ out_rsrc_t chunk_out_rsrc(void *out_, uint64_t slot, 
 // is cleared for the extraction (the walk still uses the real one), which also leaves an Xor section's state as
 // the crate's XorSink leaves it (src/sink.rs:271-275).  `tail_from` = the first LDS address from which an octet
 // start is within 33 bytes of the vector's end (beyond every address for sections that end further away).
-struct NoPreStore { __device__ __forceinline__ void operator()() const {} };
-// `pre_store` (MODE_DECODE) runs once, in front of the chunk's first burst of output stores: the caller waits there
-// for whatever loads it has in flight.  A wait for loads behind a store has to drain the store as well (one counter
-// for both, no order between the two kinds), and a drained store is a full write round trip.
-template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0, class PreStore = NoPreStore>
+template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
                                               uint32_t &mask_hi, out_rsrc_t orsrc, uint32_t ooff_in,
-                                              int32_t tail_from = 0x7fffffff, PreStore pre_store = PreStore()) {
+                                              int32_t tail_from = 0x7fffffff) {
     constexpr int W = ETYPE == CVEC_U64 ? 8 : 4;
     using U = typename Elem<W>::U;
     const uint32_t q = lane & 3;
@@ -280,16 +276,8 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
         }
         // ---- per-octet constants ---------------------------------------------------------------------------
         o.t4 = nw << 2; // trailing zero bits (a 32-bit shift uses bits 4:0 of its count; bits 5:4 only matter to section_exact and 64-bit)
-        uint32_t mask_x = mask; // the mask the extraction sees
-        if constexpr (TAILREF) {
-            // 5..8 nibbles ((nw >> 6) == 1; wider octets go to section_exact / fail) within 33 bytes of the vector's end;
-            // a 64-bit octet only if it takes the 32-bit unpacker (4n + tz <= 32)
-            bool drop = (int32_t)pa_cur >= tail_from && (nw >> 6) == 1u;
-            if constexpr (W == 8) drop = drop && n4 + ((nw & 15u) << 2) <= 32u;
-            mask_x = drop ? 0u : mask;
-        }
-        o.sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask_x, q2, 1u);     // all ones iff element 2q is stored
-        o.sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask_x, q2 + 1u, 1u);
+        o.sm0 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2, 1u);     // all ones iff element 2q is stored
+        o.sm1 = (uint32_t)__builtin_amdgcn_sbfe((int)mask, q2 + 1u, 1u);
         if constexpr (W == 4) racc |= nw & (o.sm0 | o.sm1); // the quad's lanes cover every stored element
         o.sh1 = n4 & o.sm0; // the second field lies n4 bits further on if the first one is stored
         if constexpr (W == 4) {
@@ -297,6 +285,15 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             o.fm = 0xffffffffu >> ((32u - n4) & 31u);
         } else {
             o.fm = ~0ull >> ((64u - n4) & 63u);
+        }
+        if constexpr (TAILREF) {
+            // An octet of 5 .. 8 nibbles within 33 bytes of the vector's end yields zeros: its fields are masked out
+            // (the walk and the stored-element bits above keep the real mask).  5 nibbles or more is n4 >= 20; an
+            // octet of more than 8 never gets here with a result that counts (32-bit sections: it is flagged for
+            // section_exact above and fails there; 64-bit ones take the 64-bit unpacker, tested by 4n + tz <= 32).
+            bool drop = (int32_t)pa_cur >= tail_from && n4 >= 20u;
+            if constexpr (W == 8) drop = drop && n4 + ((nw & 15u) << 2) <= 32u;
+            o.fm = drop ? (U)0 : o.fm;
         }
     };
 
@@ -391,7 +388,6 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             hold[2 * (k % HOLD)] = x0;
             hold[2 * (k % HOLD) + 1] = x1;
             if (k % HOLD == HOLD - 1) {
-                if (k == HOLD - 1) pre_store();
 #pragma unroll
                 for (int j = 0; j < HOLD; j++) {
                     const U y0 = hold[2 * j], y1 = hold[2 * j + 1];

@@ -20,7 +20,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFGS = ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5sin", "cfg5mix", "bench"]
-MODES = {"0": "filter (one-of / float zero)", "1": "decode", "2": "filter + masks", "3": "filter (bit pattern)"}
+MODES = {"0": "filter (one-of / float zero)", "1": "decode", "2": "filter + masks", "3": "filter (bit pattern)",
+         "4": "filter + masks (bit pattern)"}
 
 
 def short(name):
@@ -33,7 +34,9 @@ def short(name):
     et = {"16": "u64", "17": "u32", "18": "f32"}.get(args[0].replace("(int)", ""), args[0])
     if k in ("k_sections", "k_vstream") and len(args) >= 3:
         mode = MODES.get(args[1].replace("(int)", ""), args[1])
-        return "%s<%s, %s, %s values>" % (k, et, mode, args[2].replace("(int)", ""))
+        shape = ", %s KiB%s" % (args[3].replace("(int)", ""), ", reference tail rule" if len(args) > 4 and args[4].replace("(int)", "") == "1" else "") \
+            if len(args) > 3 and k == "k_sections" else ""
+        return "%s<%s, %s, %s values%s>" % (k, et, mode, args[2].replace("(int)", ""), shape)
     return "%s<%s>" % (k, ", ".join([et] + args[1:]))
 
 
