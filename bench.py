@@ -246,8 +246,8 @@ def main():
     torch.cuda.synchronize()
     # per-kernel HIP events on the launch stream for the first steps of the timed region only: six event
     # records cost ~0.018 ms per step, which would be charged to every step's wall time otherwise
-    # (at most a fifth of the steps: a short run is not dominated by its own instrumentation)
-    N.check(lib.cvec_timing_begin(max(1, min(args.steps // 5, args.event_steps))))
+    # (at most a tenth of the steps, two at least: a short run is not dominated by its own instrumentation)
+    N.check(lib.cvec_timing_begin(max(2, min(args.steps // 10, args.event_steps))))
     t0 = time.perf_counter()
     last = 0
     for _ in range(args.steps):
