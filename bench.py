@@ -358,7 +358,7 @@ def main():
                                                         for r in out["extra"]["configs"]) and \
                     all(v.get("exact", True) for v in out["extra"]["operations"].values() if isinstance(v, dict)) and \
                     all(out["extra"][k] for k in ("decode_bit_exact_vs_input", "filter_two_steps_in_flight_exact",
-                                                  "filter_resident_index_same_count"))
+                                                  "filter_resident_index_same_count", "encode_all_equals_batch"))
                 if not out["extra"]["all_configs_exact"]:
                     print("bench.py: a configuration's filter count differs from the direct count (see extra.configs)",
                           file=sys.stderr, flush=True)
@@ -388,8 +388,17 @@ def side_measurements(torch, cv, batch, values, elem_off, raw_bytes, check_pred)
     ok = torch.equal((values + 2.5).view(torch.int32), out[:values.numel()].view(torch.int32))
     ex["decode_bit_exact_vs_input"] = bool(ok)
     del out
-    t = _time_gpu(torch, lambda: cv.encode_device("f32", values, elem_off), 5)
+    # encode_all as an ingest loop runs it: outputs and workspace allocated once, calls enqueued back to back
+    # (cvec_encode_dev neither allocates nor synchronises); the bytes must equal the batch that the headline reads
+    ebuf = cv.EncodeBuffers("f32", batch.n_vectors, values.numel())
+    t = _time_gpu(torch, lambda: cv.encode_device_async(ebuf, values, elem_off), 10)
     ex["encode_all_GBs"] = round(raw_bytes / t / 1e9, 2)
+    ex["encode_all_equals_batch"] = bool(int(ebuf.result[0].item()) == batch.n_bytes and
+                                         torch.equal(ebuf.d_bytes[:batch.n_bytes], batch.d_bytes[:batch.n_bytes]) and
+                                         torch.equal(ebuf.d_byte_off, batch.d_byte_off))
+    del ebuf
+    t = _time_gpu(torch, lambda: cv.encode_device("f32", values, elem_off), 5)
+    ex["encode_all_with_allocation_and_readback_GBs"] = round(raw_bytes / t / 1e9, 2)
     # two independent filter steps in flight on two streams (the short index / finalize kernels and the
     # launch gaps of one step hide behind the section kernel of the other)
     pred = cv.make_pred(cv.F32, PRED)
@@ -612,7 +621,11 @@ def config_table(torch, cv, N):
         eo = torch.arange(nvec + 1, device="cuda", dtype=torch.int64) * length
         raw = vals.numel() * vals.element_size()
         batch = cv.encode_device(tname, vals, eo)
-        t_enc = _time_gpu(torch, lambda: cv.encode_device(tname, vals, eo), 5)
+        ebuf = cv.EncodeBuffers(tname, nvec, vals.numel())
+        t_enc = _time_gpu(torch, lambda: cv.encode_device_async(ebuf, vals, eo), 10)
+        enc_ok = bool(int(ebuf.result[0].item()) == batch.n_bytes and
+                      torch.equal(ebuf.d_bytes[:batch.n_bytes], batch.d_bytes[:batch.n_bytes]))
+        del ebuf
         out = torch.empty(batch.n_sections * 256, dtype=vals.dtype, device="cuda")
         masks = torch.empty(batch.n_sections * 32, dtype=torch.uint8, device="cuda")
         res = batch.result_buffer()
@@ -638,9 +651,9 @@ def config_table(torch, cv, N):
         pop = int(_popcount_u8(torch, masks))
         exact = {"reference_predicate": bool(got == want), "occurring_predicate": occ, "occurring_count": got_occ,
                  "occurring_count_expected": want_occ, "mask_pass_count": got_occ_m, "mask_bits_set": pop,
-                 "decode_equals_values_plus_const": dec_ok}
+                 "decode_equals_values_plus_const": dec_ok, "encode_repeatable": enc_ok}
         exact["all"] = bool(got == want and got_occ == want_occ and got_occ_m == want_occ and pop == want_occ and
-                            want_occ > 0 and dec_ok)
+                            want_occ > 0 and dec_ok and enc_ok)
         k_fil = kernel_ms(lambda: batch.filter_count_async(p, result=res), 20)
         k_dec = kernel_ms(lambda: batch.decode_async(out, add_const=add_const), 10)
         dom = max(k_fil)

@@ -3,7 +3,8 @@ the C ABI of include/cvec.h, with the reference crate's API names on top (see sr
 the reference for the list this mirrors)."""
 from ._native import (CodingError, F32, U32, U64, LIB_PATH, lib)
 from ._native import set_tail_rule
-from .batch import (DeviceBatch, EncodedBatch, FilteredColumn, encode_batch, encode_device, etype_of, make_pred,
+from .batch import (DeviceBatch, EncodeBuffers, EncodedBatch, FilteredColumn, encode_batch, encode_device,
+                    encode_device_async, etype_of, make_pred,
                     multi_filter, multi_filter_count)
 from .filter import EqualsSink, MultiVectorFilter, OneOfSink, VectorFilter, count_hits, match_positions
 from . import stream

@@ -476,6 +476,37 @@ def encode_device(etype, d_values, d_elem_off, n_elements_total=None):
     return DeviceBatch(etype, d_bytes, d_byte_off, d_sec_base, n, int(r[3]), int(r[0]))
 
 
+class EncodeBuffers:
+    """Preallocated outputs and workspace of encode_device_async for batches of up to n vectors / n_el elements:
+    a caller that encodes batch after batch (an ingest loop) allocates once and never synchronises."""
+
+    def __init__(self, etype, n, n_el, device="cuda"):
+        self.etype = etype_of(etype)
+        L = N.lib()
+        cap = L.cvec_max_encoded_bytes(self.etype, n, n_el)
+        self.n, self.n_el = int(n), int(n_el)
+        self.d_bytes = torch.empty(((cap + 255) // 256) * 256, dtype=torch.uint8, device=device)
+        self.d_byte_off = torch.empty(n + 1, dtype=torch.int64, device=device)
+        self.d_sec_base = torch.empty(n + 1, dtype=torch.int64, device=device)
+        self.ws = torch.empty(L.cvec_encode_workspace_bytes(n, n_el), dtype=torch.uint8, device=device)
+        self.result = torch.zeros(N.RESULT_WORDS, dtype=torch.int64, device=device)
+
+
+def encode_device_async(bufs, d_values, d_elem_off, n_elements_total=None):
+    """Vector*Appender::encode_all for a batch in HBM, enqueued on the current stream without any host
+    synchronisation or allocation: blob, byte_off, sec_base go to `bufs` (EncodeBuffers), bufs.result = [bytes, 0, 0,
+    sections] once the stream has run.  Returns bufs."""
+    n = d_elem_off.numel() - 1
+    n_el = int(d_values.numel()) if n_elements_total is None else int(n_elements_total)
+    if n > bufs.n or n_el > bufs.n_el:
+        raise N.CodingError(N.ERR_CAPACITY, "the buffers hold %d vectors / %d elements" % (bufs.n, bufs.n_el))
+    with torch.cuda.device(d_values.device):
+        N.check(N.lib().cvec_encode_dev(bufs.etype, _ptr(d_values), _ptr(d_elem_off), n, n_el, _ptr(bufs.d_bytes),
+                                        bufs.d_bytes.numel(), _ptr(bufs.d_byte_off), _ptr(bufs.d_sec_base),
+                                        _ptr(bufs.result), _ptr(bufs.ws), bufs.ws.numel(), _stream_ptr()))
+    return bufs
+
+
 def encode_batch(etype, values, elem_off):
     """Host arrays in, host EncodedBatch out (one H2D, encode on the GPU, one D2H)."""
     etype = etype_of(etype)
