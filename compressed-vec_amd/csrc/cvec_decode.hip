@@ -399,7 +399,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     u32x4 R[PIECES];
     auto issue_loads = [&](const ChunkPlan &c) {
 #ifdef CVEC_PROBES
-        const uint32_t span_bytes = sa._pad == 5 ? 0u : c.nch * 16u; // probe build: the loop without HBM traffic
+        const uint32_t span_bytes = (sa._pad == 5 || sa._pad == 7) ? 0u : c.nch * 16u; // probe build: 5 = no staging loads (7: and no output)
 #else
         const uint32_t span_bytes = c.nch * 16u;
 #endif
@@ -420,12 +420,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         }
     };
 
-#pragma unroll
-    for (int i = 0; i < PIECES; i++) R[i] = u32x4{0, 0, 0, 0};
-    // The first pass of the loop has an empty current chunk: it only plans and loads chunk 0.
     uint64_t s_cur = sA, s_next = sA;
-    ChunkPlan cur;
-    cur.gb = 0; cur.n = 0; cur.nch = 0; cur.rel = 0; cur.len = 0; cur.kind = K_SKIP; cur.tail_from = 0x7fffffff;
     // the wave's next range is asked for one range ahead: the counter's answer has a whole range to arrive
     uint32_t ticket = 0;
     // the counter this wave draws from: one of its XCD's (n_groups / 8 per XCD, so that a counter's line stays in one
@@ -452,25 +447,13 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     // A use of the first descriptor ahead of the loop: entering the loop with that load in flight would
     // put a full wait in front of the plan in every pass, right behind the deferred store.
     asm volatile("" ::"v"(d_next));
-    for (;;) {
-        // ---- registers -> staging region ---------------------------------------------------------------------
-        {
-            u32x4 *dst = (u32x4 *)data;
-#pragma unroll
-            for (int i = 0; i < PIECES; i++) dst[64 * i + lane] = R[i];
-        }
-        __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
-        if (res_pending) { sec_res[res_slot] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
-        res_pending = false;
-        if constexpr (mode_has_masks(MODE)) {
-            // one 8-byte store per lane: the quads of a chunk write 16 x 32 contiguous bytes
-            if (mk_pending) *(uint2 *)(masks + res_slot * 32 + 8 * (lane & 3)) = uint2{mk_lo, mk_hi};
-            mk_pending = false;
-        }
-        // ---- plan the next chunk and start its loads ------------------------------------------------------------
-        // (unconditional, so that the staging registers never become conditionally assigned: past the
-        // wave's range the plan is empty and the loads fetch nothing)
-        ChunkPlan nxt = plan(s_next, d_next);
+    // ---- plan the next chunk and start its loads ----------------------------------------------------------------
+    // (the loads are unconditional, so that the staging registers never become conditionally assigned: past the
+    // wave's range the plan is empty and the loads fetch nothing)
+    ChunkPlan nxt;
+    uint64_t s_after;
+    auto advance = [&]() {
+        nxt = plan(s_next, d_next);
         if constexpr (MODE == MODE_FILTER || mode_has_masks(MODE)) {
             // Behind a selective gate most chunks are closed as a whole: their results (count 0, empty
             // masks) are written here and the wave moves on, asking for the descriptors and gate masks
@@ -502,7 +485,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         }
         // where the chunk after the next one starts: behind it, or in the wave's next range once this one is used up
         // (ahead of the staging loads: the counter's answer is then the only thing the wait for it can wait for)
-        uint64_t s_after = s_next + nxt.n;
+        s_after = s_next + nxt.n;
         if (dyn && s_after >= sB && nxt.n != 0) {
             uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
             bool ok = t < quota(group);
@@ -536,9 +519,43 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         }
         issue_loads(nxt);
         d_next = load_desc(s_after);
+    };
+    // Everything the wave has in flight (staging loads, next descriptor, counter's answer) passes through here:
+    // the compiler puts its waits for them at this point.
+    auto landed = [&]() {
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) asm volatile("" ::"v"(R[i]));
+        asm volatile("" ::"v"(d_next), "v"(ticket));
+    };
+    // Chunk 0 is planned and loaded ahead of the loop, and waited for: every pass of the loop then has a chunk to
+    // work on, and the loop is entered with nothing in flight.  (With a first pass that only loads, the loop body
+    // has a way around the octet loop on which loads are in flight at its end; merged with the way through the
+    // octet loop, whose output stores are in flight there, the compiler has to drain everything at the end of
+    // every pass, and the decode pass waits for its own stores once per chunk.)
+    advance();
+    landed();
+    ChunkPlan cur = nxt;
+    s_cur = s_next;
+    s_next = s_after;
+    while (cur.n != 0) {
+        // ---- registers -> staging region ---------------------------------------------------------------------
+        {
+            u32x4 *dst = (u32x4 *)data;
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) dst[64 * i + lane] = R[i];
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the store below the staging writes (and their wait)
+        if (res_pending) { sec_res[res_slot] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
+        res_pending = false;
+        if constexpr (mode_has_masks(MODE)) {
+            // one 8-byte store per lane: the quads of a chunk write 16 x 32 contiguous bytes
+            if (mk_pending) *(uint2 *)(masks + res_slot * 32 + 8 * (lane & 3)) = uint2{mk_lo, mk_hi};
+            mk_pending = false;
+        }
+        advance();
         // ---- walk + decode the current chunk ----------------------------------------------------------------------
         const bool has_octets = cur.kind == K_NP || cur.kind == K_DELTA || cur.kind == K_XOR || cur.kind == K_RAW;
-        if (MODE != MODE_DECODE && cur.n != 0 && __ballot(has_octets) == 0) {
+        if (MODE != MODE_DECODE && __ballot(has_octets) == 0) {
             // A chunk of Null / Const / gated sections only (sparse vectors, or a column behind a
             // selective one): no octet to walk, every section's count and mask follow from its kind
             // (src/filter.rs:222-223, :104-106; a Const section is 256 copies of one value).
@@ -553,14 +570,14 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
                 mk_pending = cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
             }
 #ifdef CVEC_PROBES
-        } else if (cur.n != 0 && sa._pad != 1) { // probe build: 1 = stage the bytes but skip the octet loop
+        } else if (sa._pad != 1) { // probe build: 1 = stage the bytes but skip the octet loop
 #else
-        } else if (cur.n != 0) {
+        } else {
 #endif
             uint32_t ooff;
 #ifdef CVEC_PROBES
             // probe build: 2 = the decode pass with every store aimed past its descriptor (issued, then dropped)
-            const out_rsrc_t orsrc = sa._pad == 2 ? chunk_out_rsrc<W, MODE_FILTER>(out_, s_cur + sec, lane, ooff)
+            const out_rsrc_t orsrc = (sa._pad == 2 || sa._pad == 7) ? chunk_out_rsrc<W, MODE_FILTER>(out_, s_cur + sec, lane, ooff)
                                                   : chunk_out_rsrc<W, MODE>(out_, s_cur + sec, lane, ooff);
 #else
             const out_rsrc_t orsrc = chunk_out_rsrc<W, MODE>(out_, s_cur + sec, lane, ooff);
@@ -569,6 +586,11 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
             const int32_t tail_from = TAILREF != 0 && cur.tail_from != 0x7fffffff ? (int32_t)lds_base + cur.tail_from : 0x7fffffff;
             const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF>(
                 data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from);
+            // Decode: the next chunk's bytes are waited for here, behind the chunk's output stores in program order.
+            // The counter of memory operations retires in order, so this wait does not include those stores, and
+            // the end of the pass is reached with only stores in flight, which the next pass never waits for (its
+            // own loads are issued behind them, but they have had a whole chunk's time by then).
+            if constexpr (MODE == MODE_DECODE) landed();
             if constexpr (W == 4) {
                 const unsigned long long odd_m = __ballot(odd); // a lane only sees the octets that store its own elements
                 if (odd_m != 0) {
@@ -580,7 +602,6 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
             res_pending = sec < cur.n && (lane & 3) == 0;
             mk_pending = sec < cur.n && cur.kind != K_SKIP && cur.kind != K_ILLEGAL;
         }
-        if (nxt.n == 0) break;
         s_cur = s_next;
         cur = nxt;
         s_next = s_after;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box: SQ counter passes over the decode pass of one configuration (tools/path_probe.py <cfg>
+# slots decode), each counter set in its own rocprofv3 run.  usage: tools/pmc_decode.sh <tag> [cfg]; output under
+# gpurun_out/<tag>_*; tools/pmc_summary.py <tag> prints the per-kernel averages.
+set -e
+TAG=$1
+CFG=${2:-cfg1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+export PROBE_WARM=3 PROBE_STEPS=5
+run() { # name, counters
+  timeout -s KILL 120 rocprofv3 --pmc $2 -d $R/gpurun_out/${TAG}_$1 -o pmc --output-format csv -- python3 $R/tools/path_probe.py $CFG slots decode > $R/gpurun_out/${TAG}_$1.log 2>&1
+}
+run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_WR"
+run sq2 "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INST_LEVEL_VMEM SQ_WAVES"

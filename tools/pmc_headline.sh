@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 export PROBE_WARM=3 PROBE_STEPS=5
 run() { # name, counters
-  timeout -s KILL 120 rocprofv3 --pmc $2 -d $R/gpurun_out/${TAG}_$1 -o pmc --output-format csv -- python3 $R/tools/path_probe.py $CFG slots filter > $R/gpurun_out/${TAG}_$1.log 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc $2 -d $R/gpurun_out/${TAG}_$1 -o pmc --output-format csv -- python3 $R/tools/path_probe.py $CFG slots ${OP:-filter} > $R/gpurun_out/${TAG}_$1.log 2>&1
 }
 run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"
 run sq2 "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"
