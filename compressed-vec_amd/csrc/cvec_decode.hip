@@ -299,7 +299,10 @@ hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_
 // No barriers; the only traffic between waves are the range counters.
 // TAILREF: the reference crate's tail decoder instead of the format's rule for the last octets of a vector (see
 // process_chunk); `tail` = the index pass's per-section distances to the vector's end.
-template <int ETYPE, int MODE, int NPRED, int PIECES, int TAILREF = 0>
+// WIDE (decode passes over small sections): a staging holds up to 64 sections instead of 16 and is worked off in
+// up to four rounds of 16, so the bytes of the next staging have up to four octet loops' time to arrive behind the
+// output stores that fill the CU's memory pipeline (one descriptor per lane instead of one per quad).
+template <int ETYPE, int MODE, int NPRED, int PIECES, int TAILREF = 0, int WIDE = 0>
 __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec_wg_per_cu(PIECES), sec_wg_per_cu(PIECES)))) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
@@ -333,6 +336,10 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     uint8_t *data = sm.data[wave];
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)data);
     const uint32_t sec = (uint32_t)lane >> 2;
+    static_assert(WIDE == 0 || MODE == MODE_DECODE, "wide stagings are a decode shape");
+    // the section of a staging whose descriptor and plan the lane holds: its quad's, or (WIDE) its own
+    const uint32_t pl = WIDE ? (uint32_t)lane : sec;
+    constexpr uint32_t STAGE_SECS = WIDE ? 64u : (uint32_t)TILE;
 
     // `gate` (a pass over a resident index only; otherwise the index pass has applied it already): the
     // 256-bit mask of the same slot of an earlier column.  Lane q of the quad looks at its quarter; a
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     // bit-pattern mode and decode keep the pointer out of their loops.
     const uint8_t *const gate_ = (MODE == MODE_FILTER || mode_has_masks(MODE)) ? gate : nullptr;
     auto load_desc = [&](uint64_t s) -> uint64_t {
-        uint64_t d = s + sec < sB ? desc[s + sec] : desc_pack(0, 0, K_SKIP);
+        uint64_t d = s + pl < sB ? desc[s + pl] : desc_pack(0, 0, K_SKIP);
         if (gate_ != nullptr) {
             uint32_t any = 0;
             if (s + sec < sB) {
@@ -357,10 +364,10 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     auto plan = [&](uint64_t s, uint64_t d) -> ChunkPlan {
         ChunkPlan c;
         const uint64_t left = s < sB ? sB - s : 0;
-        const uint32_t avail = (uint32_t)(left < (uint64_t)TILE ? left : (uint64_t)TILE);
+        const uint32_t avail = (uint32_t)(left < (uint64_t)STAGE_SECS ? left : (uint64_t)STAGE_SECS);
         const uint64_t off = desc_off(d);
         // gated sections need no bytes: the span runs from the first to the last section that does
-        const bool wants = sec < avail && desc_kind(d) != K_GATED;
+        const bool wants = pl < avail && desc_kind(d) != K_GATED;
         const unsigned long long mw = __ballot(wants);
         const int f = mw ? (int)__builtin_ctzll(mw) : 0;
         const uint64_t off0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(off >> 32), f) << 32) |
@@ -374,19 +381,21 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         const uint64_t endl = off + c.len - c.gb; // wraps to a huge value if off < gb
         const bool fits = !wants || endl <= (uint64_t)region_span(PIECES);
         const unsigned long long m = __ballot(fits);
-        uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> 2;
+        uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> (WIDE ? 0 : 2);
         c.n = n < avail ? n : avail;
+        if (WIDE && c.n > (uint32_t)TILE) c.n &= ~((uint32_t)TILE - 1u); // whole rounds of 16, the rest starts the next staging
         // section offsets do not decrease with the slot number, so the span ends with the last of the
         // chunk's sections that wants bytes
-        const unsigned long long mn = c.n >= 16 ? mw : mw & ((1ull << (4 * c.n)) - 1ull);
+        constexpr uint32_t LANES_PER_SEC = WIDE ? 1u : 4u;
+        const unsigned long long mn = c.n * LANES_PER_SEC >= 64u ? mw : mw & ((1ull << (LANES_PER_SEC * c.n)) - 1ull);
         const uint32_t e = mn ? __builtin_amdgcn_readlane((uint32_t)endl, 63 - (int)__builtin_clzll(mn)) : 0u;
         c.nch = (e + 15) >> 4;
         c.rel = (uint32_t)(off - c.gb);
-        c.kind = sec < c.n ? desc_kind(d) : K_SKIP;
+        c.kind = pl < c.n ? desc_kind(d) : K_SKIP;
         c.tail_from = 0x7fffffff;
         if constexpr (TAILREF != 0) {
             // (a load per chunk, issued with the chunk's staging loads and used one loop pass later)
-            const uint32_t td = sec < c.n ? tail[s + sec] : 255u;
+            const uint32_t td = pl < c.n ? tail[s + pl] : 255u;
             if (td < 34u) c.tail_from = (int32_t)(c.rel + c.len + td) - 33;
         }
         return c;
@@ -537,7 +546,54 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     ChunkPlan cur = nxt;
     s_cur = s_next;
     s_next = s_after;
-    while (cur.n != 0) {
+    while (WIDE && cur.n != 0) {
+        {
+            u32x4 *dst = (u32x4 *)data;
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) dst[64 * i + lane] = R[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        // rounds of 16 sections: the quad takes the plan of its section from the lane that holds it
+#pragma nounroll
+        for (uint32_t j0 = 0; j0 < cur.n; j0 += TILE) {
+            const int src = (int)(j0 + sec);
+            const bool live = (uint32_t)src < cur.n;
+            const uint32_t kind_q = live ? (uint32_t)__shfl((int)cur.kind, src, 64) : (uint32_t)K_SKIP;
+            const uint32_t rel_q = (uint32_t)__shfl((int)cur.rel, src, 64), len_q = (uint32_t)__shfl((int)cur.len, src, 64);
+            int32_t tail_from = 0x7fffffff;
+            if constexpr (TAILREF != 0) {
+                const int32_t tf = __shfl(cur.tail_from, src, 64);
+                if (live && tf != 0x7fffffff) tail_from = (int32_t)lds_base + tf;
+            }
+            uint32_t ooff;
+#ifdef CVEC_PROBES
+            const out_rsrc_t orsrc = (sa._pad == 2 || sa._pad == 7) ? chunk_out_rsrc<W, MODE_FILTER>(out_, s_cur + j0 + sec, lane, ooff)
+                                                                    : chunk_out_rsrc<W, MODE>(out_, s_cur + j0 + sec, lane, ooff);
+#else
+            const out_rsrc_t orsrc = chunk_out_rsrc<W, MODE>(out_, s_cur + j0 + sec, lane, ooff);
+#endif
+            #ifndef CVEC_WIDE_PAIRS
+#define CVEC_WIDE_PAIRS 1
+#endif
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF, CVEC_WIDE_PAIRS != 0>(
+                data, lds_base, kind_q, rel_q, len_q, live, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from);
+            if constexpr (W == 4) {
+                const unsigned long long odd_m = __ballot(odd);
+                if (odd_m != 0) {
+                    if ((odd_m >> ((uint32_t)lane & ~3u)) & 0xfull) section_exact<ETYPE, MODE, NPRED, TAILREF>(data, lds_base, kind_q, rel_q, len_q, lane, pa, sa, res_word,
+                                                               mk_lo, mk_hi, orsrc, ooff, tail_from);
+                }
+            }
+            // (stored at once: the waits of this loop are for loads that are older than any store of the staging)
+            if (live && (lane & 3) == 0) { sec_res[s_cur + j0 + sec] = res_word; acc_cnt += res_word & 0xffffu; acc_bad |= res_word; }
+        }
+        landed();
+        s_cur = s_next;
+        cur = nxt;
+        s_next = s_after;
+    }
+    while (!WIDE && cur.n != 0) {
         // ---- registers -> staging region ---------------------------------------------------------------------
         {
             u32x4 *dst = (u32x4 *)data;
@@ -813,6 +869,9 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 3) tiny = count_only;
         if (shape_env == 4) tiny = false;
         if (tiny) small = false;
+        bool wide = mode == MODE_DECODE && n_bytes != 0 && (n_bytes / ns) * 32 + 2 * 16 <= region_span(REGION_PIECES);
+        if (shape_env == 5) wide = false;
+        if (shape_env == 6) wide = mode == MODE_DECODE;
         const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
         uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
 #ifdef CVEC_PROBES
@@ -838,6 +897,8 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
 #endif
         if (work != nullptr) per = (per + rpw - 1) / rpw;
         per = (per + TILE - 1) / TILE * TILE;
+        // Wide stagings (decode over sections of which at least 32 fit the region): ranges are whole stagings of 64
+        if (wide) per = (per + 63) / 64 * 64;
 #ifdef CVEC_PROBES
         static const int min_chunks = [] { const char *e = getenv("CVEC_RANGE_MIN_CHUNKS"); return e ? atoi(e) : 2; }();
 #else
@@ -858,9 +919,14 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         uint32_t bucket = 1;
         while (bucket < pb.count) bucket *= 2;
         for (uint32_t i = pb.count; i < bucket && i < CVEC_MAX_PRED_VALUES; i++) pb.v[i] = pb.v[0];
-#define CVEC_LAUNCH_SEC_P(M, N, P, T)                                                                               \
-    k_sections<ETYPE, M, N, P, T><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
+#define CVEC_LAUNCH_SEC_PW(M, N, P, T, WD)                                                                          \
+    k_sections<ETYPE, M, N, P, T, WD><<<nwg, SEC_THREADS, 0, stream>>>(d_bytes, desc, ns, per, pb, sa2, sec_res, d_masks, d_out, \
                                                                    tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached, tail)
+#define CVEC_LAUNCH_SEC_P(M, N, P, T)                                                                               \
+    do {                                                                                                            \
+        if (M == MODE_DECODE && wide) CVEC_LAUNCH_SEC_PW(M, N, P, T, (M == MODE_DECODE ? 1 : 0));                  \
+        else CVEC_LAUNCH_SEC_PW(M, N, P, T, 0);                                                                     \
+    } while (0)
 #define CVEC_LAUNCH_SEC_T(M, N, T)                                                                                  \
     do {                                                                                                            \
         if ((M == MODE_FILTER || mode_bit_compare(M)) && tiny)                                                      \
@@ -888,7 +954,10 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
             // stores stream faster (2.25 -> 2.62 TB/s on dense u32; the second template argument is the store policy
             // here).  Not below that: output that is mostly runs of one value (sparse vectors) loses a quarter.
             const uint64_t raw = ns * (uint64_t)(FIXED_LEN * 4);
-            const bool nt_out = ETYPE != CVEC_U64 && n_bytes * 20 >= raw && n_bytes * 20 <= raw * 7;
+            #ifndef CVEC_WIDE_NT
+#define CVEC_WIDE_NT 0
+#endif
+            const bool nt_out = ETYPE != CVEC_U64 && n_bytes * 20 >= raw && n_bytes * 20 <= raw * 7 && (!wide || CVEC_WIDE_NT);
             if (nt_out) CVEC_LAUNCH_SEC(MODE_DECODE, 2); else CVEC_LAUNCH_SEC(MODE_DECODE, 1);
         }
         else if (bucket == 1) {
@@ -904,6 +973,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
 #undef CVEC_LAUNCH_SEC
 #undef CVEC_LAUNCH_SEC_T
 #undef CVEC_LAUNCH_SEC_P
+#undef CVEC_LAUNCH_SEC_PW
     }
 }
 

@@ -185,7 +185,7 @@ __device__ __forceinline__ out_rsrc_t chunk_out_rsrc(void *out_, uint64_t slot, 
 // is cleared for the extraction (the walk still uses the real one), which also leaves an Xor section's state as
 // the crate's XorSink leaves it (src/sink.rs:271-275).  `tail_from` = the first LDS address from which an octet
 // start is within 33 bytes of the vector's end (beyond every address for sections that end further away).
-template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0>
+template <int ETYPE, int MODE, int NPRED, uint32_t ZPAD, int TAILREF = 0, bool PAIRS = false>
 __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_base, uint32_t kind, uint32_t rel,
                                               uint32_t len, bool live, int lane, const PredArgs &pa,
                                               const SinkArgs &sa, uint32_t &sec_result, uint32_t &mask_lo,
@@ -222,6 +222,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
     const uint32_t q2 = 2 * q;
     const uint32_t ooff = (live && kind != K_SKIP && kind != K_ILLEGAL) ? ooff_in : OOFF_NONE;
     const bool addc = sa.add_const != 0;
+    // 32-bit decode with 16-byte stores: byte offset of the lane's piece of an octet pair (see the store burst below):
+    // half q >> 1 of the pair's first (even q) or second (odd q) octet
+    const bool oddq = (q & 1u) != 0;
+    const uint32_t ooff16 = ooff - 8u * q + 16u * (q >> 1) + 32u * (q & 1u);
 
     // The loop is software-pipelined by one octet: iteration k runs the front half of octet k (walk
     // chain, header reads of octet k+1, address + reads of the lane's fields, per-octet constants) and
@@ -300,7 +304,10 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
 #ifndef CVEC_HOLD
 #define CVEC_HOLD 4
 #endif
-    constexpr int HOLD = CVEC_HOLD; // octets of decoded values held back per store burst (MODE_DECODE)
+#ifndef CVEC_HOLD_PAIRS
+#define CVEC_HOLD_PAIRS 4
+#endif
+    constexpr int HOLD = PAIRS ? CVEC_HOLD_PAIRS : CVEC_HOLD; // octets of decoded values held back per store burst (MODE_DECODE)
     U hold[2 * HOLD];
     // back half of octet k: `newer` LDS reads were issued after its field reads
     auto back = [&](Oct &o, int k, auto newer) {
@@ -388,17 +395,36 @@ __device__ __forceinline__ bool process_chunk(const uint8_t *data, uint32_t lds_
             hold[2 * (k % HOLD)] = x0;
             hold[2 * (k % HOLD) + 1] = x1;
             if (k % HOLD == HOLD - 1) {
+                typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
+                if constexpr (W == 4 && PAIRS) {
+                    // 32-bit elements, 16-byte stores: the lanes of a pair (q, q ^ 1) trade halves of two consecutive
+                    // octets: the even lane stores 16 bytes of the first octet (its own 8 and the odd lane's), the odd
+                    // lane 16 bytes of the second (the even lane's 8 and its own), so a quad's store covers 64
+                    // contiguous bytes, as for 64-bit elements, with half the store instructions.
+                    static_assert(HOLD % 2 == 0, "octets are stored in pairs");
 #pragma unroll
-                for (int j = 0; j < HOLD; j++) {
-                    const U y0 = hold[2 * j], y1 = hold[2 * j + 1];
-                    const uint32_t at = ooff + (uint32_t)(8 * (k - (HOLD - 1) + j) * W);
-                    if constexpr (W == 4) {
-                        typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{y0, y1}, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
-                    } else {
-                        typedef uint32_t __attribute__((__vector_size__(16))) u32x4;
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)}, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
+                    for (int j = 0; j < HOLD; j += 2) {
+                        const uint32_t a0 = hold[2 * j], a1 = hold[2 * j + 1], b0 = hold[2 * j + 2], b1 = hold[2 * j + 3];
+                        const uint32_t pa0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a0, 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, true);
+                        const uint32_t pa1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a1, 0xb1, 0xf, 0xf, true);
+                        const uint32_t pb0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b0, 0xb1, 0xf, 0xf, true);
+                        const uint32_t pb1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)b1, 0xb1, 0xf, 0xf, true);
+                        const u32x4 y = oddq ? u32x4{pb0, pb1, b0, b1} : u32x4{a0, a1, pa0, pa1};
+                        const uint32_t at = ooff16 + (uint32_t)(32 * (k - (HOLD - 1) + j));
+                        __builtin_amdgcn_raw_buffer_store_b128(y, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < HOLD; j++) {
+                        const U y0 = hold[2 * j], y1 = hold[2 * j + 1];
+                        const uint32_t at = ooff + (uint32_t)(8 * (k - (HOLD - 1) + j) * W);
+                        if constexpr (W == 4) {
+                            typedef uint32_t __attribute__((__vector_size__(8))) u32x2;
+                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{y0, y1}, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                u32x4{(uint32_t)y0, (uint32_t)(y0 >> 32), (uint32_t)y1, (uint32_t)(y1 >> 32)}, orsrc, at, 0, OutPolicy<MODE, NPRED>::AUX);
+                        }
                     }
                 }
             }

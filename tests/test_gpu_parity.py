@@ -1158,6 +1158,71 @@ def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle, top
     assert onlybig.filter_count(int(big[1][9])) == int((np.concatenate(big) == big[1][9]).sum())
 
 
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_wide_decode_stagings_vs_oracle(cv, oracle, tname):
+    """Decode passes over batches whose sections average at most a few hundred bytes stage up to 64 sections at
+    once and work them off in rounds of 16.  Section sizes are mixed so that stagings end after every possible
+    number of sections (tiny sections in runs, dense ones, a few incompressible vectors in between, ragged vector
+    ends, Null and Const sections), the batch is large enough for every wave to draw several ranges, bytes are
+    damaged in a few vectors, and both tail rules run; values, statuses and per-vector element counts against the
+    oracle."""
+    et, npd = ET[tname], NPD[tname]
+    rng = np.random.default_rng(4242 + et)
+    parts = []
+    for v in range(2600):
+        n = int(rng.integers(1, 1800))
+        kind = int(rng.integers(0, 10))
+        if tname == "f32":
+            if kind < 5:
+                x = (rng.integers(0, 4, size=n) * 0.5).astype(np.float32)            # few distinct bit patterns
+            elif kind < 8:
+                x = rng.integers(0, 1 << 12, size=n).astype(np.float32)
+            else:
+                x = rng.normal(size=n).astype(np.float32)                               # incompressible
+        else:
+            top = (1 << 4, 1 << 4, 1 << 9, 1 << 9, 1 << 14, 1 << 14, 1 << 20, 1 << 20, 1 << 31, 1 << 31)[kind]
+            x = rng.integers(0, top, size=n).astype(npd)
+            if kind == 9 and tname == "u64" and v % 3 == 0:
+                x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+            if v % 6 == 0:
+                x += npd(100000)
+        if v % 9 == 0:
+            x[: min(n, 512)] = 0                                                        # Null sections in front
+        if v % 13 == 0 and n > 300:
+            x[-300:] = x[-301]                                                          # a Const tail
+        parts.append(x)
+    eo = np.concatenate([[0], np.cumsum([p.size for p in parts])]).astype(np.uint64)
+    vals = np.concatenate(parts)
+    blob, bo = oracle.batch_encode(et, vals, eo)
+    blob = blob.copy()
+    for v in (3, 500, 501, 1999, 2599):                                                 # damage a byte of five vectors
+        a, b = int(bo[v]), int(bo[v + 1])
+        if b - a > 60:
+            blob[a + (b - a) * 2 // 3] ^= 0x5a
+    dev = cv.EncodedBatch(tname, blob, bo).to_device()
+    assert dev.n_sections > 6000 and dev.n_bytes // dev.n_sections * 32 + 32 <= 18 * 1024 - 64   # the wide shape's rule
+    base = {"u32": 4000000001, "u64": (1 << 63) + 77, "f32": -1.25}[tname]
+    for rule in ("format", "reference"):
+        for add in (None, base):
+            got, out_off, st = dev.decode(add_const=add, return_status=True, tail_rule=rule)
+            if rule == "reference":
+                with oracle.ref_tail_quirk():
+                    want, wst, _rc = oracle.batch_decode(et, blob, bo, out_off, add_base=add)
+            else:
+                want, wst, _rc = oracle.batch_decode(et, blob, bo, out_off, add_base=add)
+            assert np.array_equal(st, wst), (rule, add)
+            ok = np.flatnonzero(wst == 0)
+            assert ok.size >= 2590
+            for v in ok[:: 7]:
+                a, b = int(out_off[v]), int(out_off[v + 1])
+                assert np.array_equal(_bits(got[a:b]), _bits(want[a:b])), (rule, add, int(v))
+            # every good vector, in one comparison
+            keep = np.zeros(got.size, dtype=bool)
+            for v in ok:
+                keep[int(out_off[v]):int(out_off[v + 1])] = True
+            assert np.array_equal(_bits(got)[keep], _bits(want)[keep]), (rule, add)
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
