@@ -383,7 +383,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         const unsigned long long m = __ballot(fits);
         uint32_t n = m == ~0ull ? avail : (uint32_t)__builtin_ctzll(~m) >> (WIDE ? 0 : 2);
         c.n = n < avail ? n : avail;
-        if (WIDE && c.n > (uint32_t)TILE) c.n &= ~((uint32_t)TILE - 1u); // whole rounds of 16, the rest starts the next staging
+        // whole rounds of 16, the rest starts the next staging; a last round that is at least half full is kept
+        if (WIDE && c.n > (uint32_t)TILE && (c.n & ((uint32_t)TILE - 1u)) < (uint32_t)TILE / 2) c.n &= ~((uint32_t)TILE - 1u);
         // section offsets do not decrease with the slot number, so the span ends with the last of the
         // chunk's sections that wants bytes
         constexpr uint32_t LANES_PER_SEC = WIDE ? 1u : 4u;
@@ -559,11 +560,18 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         for (uint32_t j0 = 0; j0 < cur.n; j0 += TILE) {
             const int src = (int)(j0 + sec);
             const bool live = (uint32_t)src < cur.n;
-            const uint32_t kind_q = live ? (uint32_t)__shfl((int)cur.kind, src, 64) : (uint32_t)K_SKIP;
-            const uint32_t rel_q = (uint32_t)__shfl((int)cur.rel, src, 64), len_q = (uint32_t)__shfl((int)cur.len, src, 64);
+            // (all lanes take part in the exchange, whatever they do with the result: a lane that is switched off
+            // hands out zeros, and in a round that is not full the lanes that hold the plans are not live themselves;
+            // the results pass through an empty statement so that the reads stay in front of anything conditional)
+            uint32_t kind_x = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)cur.kind);
+            uint32_t rel_q = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)cur.rel);
+            uint32_t len_q = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)cur.len);
+            int32_t tf = 0x7fffffff;
+            if constexpr (TAILREF != 0) tf = __builtin_amdgcn_ds_bpermute(src << 2, cur.tail_from);
+            asm volatile("" : "+v"(kind_x), "+v"(rel_q), "+v"(len_q), "+v"(tf));
+            const uint32_t kind_q = live ? kind_x : (uint32_t)K_SKIP;
             int32_t tail_from = 0x7fffffff;
             if constexpr (TAILREF != 0) {
-                const int32_t tf = __shfl(cur.tail_from, src, 64);
                 if (live && tf != 0x7fffffff) tail_from = (int32_t)lds_base + tf;
             }
             uint32_t ooff;
@@ -869,7 +877,10 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 3) tiny = count_only;
         if (shape_env == 4) tiny = false;
         if (tiny) small = false;
-        bool wide = mode == MODE_DECODE && n_bytes != 0 && (n_bytes / ns) * 32 + 2 * 16 <= region_span(REGION_PIECES);
+        #ifndef CVEC_WIDE_MIN
+#define CVEC_WIDE_MIN 24
+#endif
+        bool wide = mode == MODE_DECODE && n_bytes != 0 && (n_bytes / ns) * CVEC_WIDE_MIN + 2 * 16 <= region_span(REGION_PIECES);
         if (shape_env == 5) wide = false;
         if (shape_env == 6) wide = mode == MODE_DECODE;
         const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));

@@ -1200,7 +1200,7 @@ def test_wide_decode_stagings_vs_oracle(cv, oracle, tname):
         if b - a > 60:
             blob[a + (b - a) * 2 // 3] ^= 0x5a
     dev = cv.EncodedBatch(tname, blob, bo).to_device()
-    assert dev.n_sections > 6000 and dev.n_bytes // dev.n_sections * 32 + 32 <= 18 * 1024 - 64   # the wide shape's rule
+    assert dev.n_sections > 6000 and dev.n_bytes // dev.n_sections * 24 + 32 <= 18 * 1024 - 64   # the wide shape's rule
     base = {"u32": 4000000001, "u64": (1 << 63) + 77, "f32": -1.25}[tname]
     for rule in ("format", "reference"):
         for add in (None, base):
