@@ -2,7 +2,7 @@
 """Decode kernel times per configuration (HIP events of the library around its three kernels) with a check of the
 decoded values, for comparing builds:
 
-    CVEC_LIB_PATH=compressed-vec_amd/lib/<variant>.so python3 tools/decode_probe.py [cfg ...]"""
+    CVEC_LIB_PATH=compressed-vec_amd/lib/<variant>.so [PROBE_READ_PATH=slots|vstream] python3 tools/decode_probe.py [cfg ...]"""
 import ctypes as C
 import os
 import sys
@@ -15,6 +15,9 @@ from compressed_vec_amd import _native as N  # noqa: E402
 import profile_op  # noqa: E402
 
 
+RP = os.environ.get("PROBE_READ_PATH") or None
+
+
 def main():
     names = sys.argv[1:] or ["cfg1", "cfg3", "cfg4", "cfg5sin", "cfg5mix"]
     lib = cv.lib()
@@ -25,12 +28,12 @@ def main():
         batch = cv.encode_device(tname, vals, eo)
         out = torch.empty(batch.n_sections * 256, dtype=vals.dtype, device="cuda")
         for _ in range(30):
-            batch.decode_async(out, add_const=add_const)
+            batch.decode_async(out, add_const=add_const, read_path=RP)
         torch.cuda.synchronize()
         iters = 20
         N.check(lib.cvec_timing_begin(iters))
         for _ in range(iters):
-            batch.decode_async(out, add_const=add_const)
+            batch.decode_async(out, add_const=add_const, read_path=RP)
         torch.cuda.synchronize()
         ms = [C.c_float(0), C.c_float(0), C.c_float(0)]
         nrec = C.c_int32(0)
