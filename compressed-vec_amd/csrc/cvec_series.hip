@@ -12,11 +12,19 @@
 //                            A run of whole null sections (append_nulls behind an empty open section, finish's
 //                            padding) is one 0x00 byte per section in the vector: such a segment is only a count per
 //                            series, whatever the length of the run
+// Merging: ragged appends that complete sections for a few series per call would leave one segment (and one offset
+// per series) per call.  Segments carry a level; as soon as MERGE_FANIN segments of one level have gathered at the
+// end of the list they are gathered into one segment of the next level (the kernels of emit(), aimed at the arena of
+// that level), and the arena of the lower level is rewound: a byte is copied once per level, a handle holds at most
+// MERGE_FANIN - 1 segments per level, and what it holds is bounded by twice its contents.  A long run of null sections
+// (more than MERGE_MAX_NULL_RUN per series on average) is never written out as bytes: everything in front of it is
+// merged into one segment that stays where it is, and so does the run.
 // seal() adds what finish() adds (the open section padded with zeros as an encoded segment, the null sections up
 // to total_num_rows as a count, src/vector.rs:344-359) and computes the byte offsets of the final vectors;
 // emit() writes, per series, one header (element and null-section counts, src/vector.rs:160-169) followed by the
 // section bytes of all segments in order.  Sections are independent of their neighbours, so the bytes equal the
 // reference appender's for the same sequence of calls.
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -60,7 +68,11 @@ struct Segment { // the arrays live in the handle's arena
     uint64_t *off = nullptr;     // n + 1
     uint64_t *null_run = nullptr; // instead of bytes / off: series v continues with null_run[v] null sections (one 0x00 byte each)
     uint64_t n_bytes = 0;
+    uint32_t level = 0;           // how many merges its contents have been through
+    bool pinned = false;          // stays as it is: a long run of null sections, or what lies in front of one
 };
+constexpr uint32_t MERGE_FANIN = 16;        // segments of one level that are merged into one of the next
+constexpr uint64_t MERGE_MAX_NULL_RUN = 64; // null sections per series (on average) up to which a run is merged as bytes
 
 // Segment storage: slabs of device memory handed out front to back.  A finish() or reset() rewinds the slabs
 // and keeps them, so a handle that is filled again and again allocates only while it grows.
@@ -336,7 +348,10 @@ struct cvec_series_appender {
     Buf enc_bytes, enc_off, enc_sec, enc_res, enc_ws;
     Buf out_size, out_off, out_nsec, out_sec, tab_off, tab_bytes, tab_null, maxlen;
     Buf up_vals, up_off;                 // device copies of host arguments (the *_host calls)
-    Arena arena;
+    Arena arena;                         // segments of level 0, the closing segments of a seal
+    std::vector<std::unique_ptr<Arena>> upper; // upper[l - 1]: the merged segments of level l
+    Arena pinned;                        // segments that are never merged again
+    uint64_t merges = 0;                 // merge operations since the handle was made
     std::vector<Segment> segs;
     std::vector<Segment> tail;           // finish()'s closing segments (open section, null run), between seal and emit
     bool uniform = true;                 // every call since the last reset gave all series the same count:
@@ -372,6 +387,8 @@ cvec_status clear_state(cvec_series_appender *a, hipStream_t st) {
     a->segs.clear();
     a->tail.clear();
     a->arena.rewind();
+    for (auto &u : a->upper) u->rewind();
+    a->pinned.rewind();
     a->sealed = 0;
     a->uniform = true;
     a->ufill = 0;
@@ -417,6 +434,9 @@ cvec_status encode_segment(cvec_series_appender *a, const void *vals, const uint
     return CVEC_OK;
 }
 
+cvec_status pin_all(cvec_series_appender *a, hipStream_t st);
+cvec_status merge_levels(cvec_series_appender *a, hipStream_t st);
+
 // Keeps the counts in a->run as a segment of null sections if any series has one.
 // `known` >= 0: the sum of the counts, which the host already knows (uniform calls).
 cvec_status null_run_segment(cvec_series_appender *a, std::vector<Segment> *to, hipStream_t st, int64_t known = -1) {
@@ -429,12 +449,119 @@ cvec_status null_run_segment(cvec_series_appender *a, std::vector<Segment> *to, 
     }
     if (total == 0) return CVEC_OK;
     Segment s;
-    SER_TRY(a->arena.take(n * 8, (void **)&s.null_run));
+    Arena *from = &a->arena;
+    if (to == &a->segs && total > MERGE_MAX_NULL_RUN * n) {
+        cvec_status cs = pin_all(a, st);
+        if (cs) return cs;
+        from = &a->pinned;
+        s.pinned = true;
+    }
+    SER_TRY(from->take(n * 8, (void **)&s.null_run));
     SER_TRY(hipMemcpyAsync(s.null_run, a->run.p, n * 8, hipMemcpyDeviceToDevice, st));
     SER_TRY(hipStreamSynchronize(st));
     s.n_bytes = total;
     to->push_back(s);
-    a->resident_bytes += n * 8;
+    if (to == &a->segs) {
+        a->resident_bytes += n * 8;
+        return merge_levels(a, st);
+    }
+    return CVEC_OK;
+}
+
+// Uploads the pointer tables of `count` segments starting at `first` of `list` (then of `list2`, if given).
+cvec_status upload_tables(cvec_series_appender *a, const Segment *first, size_t count, const std::vector<Segment> *list2,
+                          uint32_t *n_seg_out, hipStream_t st) {
+    std::vector<const uint64_t *> h_off, h_null;
+    std::vector<const uint8_t *> h_bytes;
+    for (size_t i = 0; i < count; i++) { h_off.push_back(first[i].off); h_bytes.push_back(first[i].bytes); h_null.push_back(first[i].null_run); }
+    if (list2)
+        for (const Segment &g : *list2) { h_off.push_back(g.off); h_bytes.push_back(g.bytes); h_null.push_back(g.null_run); }
+    const uint32_t n_seg = (uint32_t)h_off.size();
+    SER_TRY(a->tab_off.need((size_t)n_seg * 8));
+    SER_TRY(a->tab_bytes.need((size_t)n_seg * 8));
+    SER_TRY(a->tab_null.need((size_t)n_seg * 8));
+    if (n_seg) {
+        SER_TRY(hipMemcpyAsync(a->tab_off.p, h_off.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
+        SER_TRY(hipMemcpyAsync(a->tab_bytes.p, h_bytes.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
+        SER_TRY(hipMemcpyAsync(a->tab_null.p, h_null.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
+        SER_TRY(hipStreamSynchronize(st)); // the host vectors go out of scope
+    }
+    *n_seg_out = n_seg;
+    return CVEC_OK;
+}
+
+uint64_t segment_resident_bytes(const cvec_series_appender *a, const Segment &g) { return g.null_run ? a->n * 8 : g.n_bytes; }
+
+// Replaces the segments [first, segs.size()) by one segment in `dst` that holds, per series, a header's worth of
+// bytes (never read: a segment is laid out like an encoded vector) and their section bytes in order, null runs
+// written out as 0x00 bytes.
+cvec_status merge_trailing(cvec_series_appender *a, size_t first, Arena &dst, uint32_t level, bool pinned, hipStream_t st) {
+    const uint64_t n = a->n;
+    const size_t count = a->segs.size() - first;
+    if (count == 0) return CVEC_OK;
+    uint32_t n_seg = 0;
+    cvec_status cs = upload_tables(a, a->segs.data() + first, count, nullptr, &n_seg, st);
+    if (cs) return cs;
+    Segment m;
+    SER_TRY(dst.take((n + 1) * 8, (void **)&m.off));
+    // (sizes as for a reader; the element counts that k_ser_sizes also derives are not used here)
+    k_ser_sizes<<<lane_blocks(n), SER_THREADS, 0, st>>>(n, 1, 0, a->len.as<uint64_t>(), a->fill.as<uint32_t>(),
+                                                        a->tab_off.as<const uint64_t *>(), a->tab_null.as<const uint64_t *>(), n_seg,
+                                                        a->out_size.as<uint64_t>(), a->out_nsec.as<uint64_t>());
+    SER_TRY(launch_exclusive_scan(a->out_size.as<uint64_t>(), n, m.off, a->scan_tmp.as<uint64_t>(), st));
+    uint64_t total = 0;
+    SER_TRY(hipMemcpyAsync(&total, m.off + n, 8, hipMemcpyDeviceToHost, st));
+    SER_TRY(hipStreamSynchronize(st));
+    SER_TRY(dst.take(total + 16, (void **)&m.bytes));
+    k_ser_gather<<<wave_blocks(n), SER_THREADS, 0, st>>>(n, a->etype, 1, 0, a->len.as<uint64_t>(), a->fill.as<uint32_t>(),
+                                                         a->nulls.as<uint32_t>(), a->tab_off.as<const uint64_t *>(),
+                                                         a->tab_bytes.as<const uint8_t *>(), a->tab_null.as<const uint64_t *>(), n_seg,
+                                                         m.off, m.bytes);
+    SER_TRY(hipGetLastError());
+    SER_TRY(hipStreamSynchronize(st)); // the sources may be overwritten once their arena is rewound
+    m.n_bytes = total;
+    m.level = level;
+    m.pinned = pinned;
+    for (size_t i = first; i < a->segs.size(); i++) a->resident_bytes -= segment_resident_bytes(a, a->segs[i]);
+    a->segs.resize(first);
+    a->segs.push_back(m);
+    a->resident_bytes += total;
+    a->merges++;
+    return CVEC_OK;
+}
+
+Arena &level_arena(cvec_series_appender *a, uint32_t level) {
+    if (level == 0) return a->arena;
+    while (a->upper.size() < level) a->upper.emplace_back(new Arena());
+    return *a->upper[level - 1];
+}
+
+// After a segment was added: while MERGE_FANIN segments of the last one's level end the list, they become one of the
+// next level.  The segments of a level lie behind every pinned segment and are all of its arena's contents.
+cvec_status merge_levels(cvec_series_appender *a, hipStream_t st) {
+    for (;;) {
+        if (a->segs.empty() || a->segs.back().pinned) return CVEC_OK;
+        const uint32_t level = a->segs.back().level;
+        size_t first = a->segs.size();
+        while (first > 0 && !a->segs[first - 1].pinned && a->segs[first - 1].level == level) first--;
+        if (a->segs.size() - first < MERGE_FANIN) return CVEC_OK;
+        cvec_status cs = merge_trailing(a, first, level_arena(a, level + 1), level + 1, false, st);
+        if (cs) return cs;
+        level_arena(a, level).rewind();
+    }
+}
+
+// In front of a long run of null sections: everything that is not pinned yet becomes one pinned segment, and the
+// arenas of all levels are free again.
+cvec_status pin_all(cvec_series_appender *a, hipStream_t st) {
+    size_t first = a->segs.size();
+    while (first > 0 && !a->segs[first - 1].pinned) first--;
+    if (first != a->segs.size()) {
+        cvec_status cs = merge_trailing(a, first, a->pinned, 0, true, st);
+        if (cs) return cs;
+    }
+    a->arena.rewind();
+    for (auto &u : a->upper) u->rewind();
     return CVEC_OK;
 }
 
@@ -481,6 +608,8 @@ cvec_status append_t(cvec_series_appender *a, const void *d_values, const uint64
         if (cs) return cs;
         a->segs.push_back(s);
         a->resident_bytes += s.n_bytes;
+        cs = merge_levels(a, st);
+        if (cs) return cs;
     } else {
         SER_TRY(hipStreamSynchronize(st)); // the caller's values may be reused when the call returns
     }
@@ -657,19 +786,10 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
         }
     }
     // pointer tables of the segments, then sizes -> offsets
-    std::vector<const uint64_t *> h_off, h_null;
-    std::vector<const uint8_t *> h_bytes;
-    for (const std::vector<Segment> *list : {&a->segs, &a->tail})
-        for (const Segment &s : *list) { h_off.push_back(s.off); h_bytes.push_back(s.bytes); h_null.push_back(s.null_run); }
-    const uint32_t n_seg = (uint32_t)h_off.size();
-    SER_TRY(a->tab_off.need((size_t)n_seg * 8));
-    SER_TRY(a->tab_bytes.need((size_t)n_seg * 8));
-    SER_TRY(a->tab_null.need((size_t)n_seg * 8));
-    if (n_seg) {
-        SER_TRY(hipMemcpyAsync(a->tab_off.p, h_off.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
-        SER_TRY(hipMemcpyAsync(a->tab_bytes.p, h_bytes.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
-        SER_TRY(hipMemcpyAsync(a->tab_null.p, h_null.data(), (size_t)n_seg * 8, hipMemcpyHostToDevice, st));
-        SER_TRY(hipStreamSynchronize(st)); // the host vectors go out of scope
+    uint32_t n_seg = 0;
+    {
+        cvec_status cs = upload_tables(a, a->segs.data(), a->segs.size(), &a->tail, &n_seg, st);
+        if (cs) return cs;
     }
     uint64_t tot[2] = {0, 0};
     if (n) {

@@ -505,7 +505,9 @@ cvec_status cvec_series_appender_seal(cvec_series_appender *a, int32_t reader, u
 cvec_status cvec_series_appender_emit_dev(cvec_series_appender *a, uint8_t *d_bytes, size_t bytes_cap,
                                           uint64_t *d_byte_off, uint64_t *d_sec_base, void *stream);
 cvec_status cvec_series_appender_unseal(cvec_series_appender *a);
-/* Device memory held: number of encoded segments, their bytes, and the bytes of open sections and offsets. */
+/* Device memory held: number of encoded segments (an append call that completes sections adds one; sixteen of a
+ * kind are merged into one, so the number stays small however many calls there were), their bytes, and the bytes of
+ * open sections and offsets. */
 cvec_status cvec_series_appender_stats(const cvec_series_appender *a, uint64_t *n_segments, uint64_t *encoded_bytes,
                                        uint64_t *state_bytes);
 

@@ -196,6 +196,48 @@ def test_series_appender_long_null_runs_cost_a_count_not_their_length(cv, oracle
     _same_vectors(batch.download(), oracles, total=total)
 
 
+@pytest.mark.parametrize("tname", ["u32", "f32"])
+def test_series_appender_merges_segments_of_ragged_appends(cv, oracle, tname):
+    """Hundreds of ragged append calls that each complete sections for a few series only: the handle merges sixteen
+    segments of one level into one of the next, so it holds a handful of segments instead of one per call, and a
+    long run of null sections in the middle stays a count (what lies in front of it is merged into one segment that
+    is never touched again).  Readers at several points and the finished vectors against the oracle's appenders."""
+    rng = np.random.default_rng({"u32": 31, "f32": 32}[tname])
+    n = 150
+    et = {"u32": oracle.U32, "f32": oracle.F32}[tname]
+    app = cv.SeriesAppender(tname, n)
+    oracles = [oracle.Appender(et, 64) for _ in range(n)]
+    most = 0
+    for step in range(620):
+        if step == 300:
+            runs = rng.integers(0, 5_000_000, size=n)        # a long run of nulls: pinned, not written out
+            app.append_nulls(runs)
+            for v, o in enumerate(oracles):
+                if runs[v]:
+                    o.append_nulls(int(runs[v]))
+        elif step % 37 == 5:
+            runs = rng.integers(0, 700, size=n) * (rng.random(n) < 0.2)   # short runs for a fifth of the series
+            app.append_nulls(runs)
+            for v, o in enumerate(oracles):
+                if runs[v]:
+                    o.append_nulls(int(runs[v]))
+        else:
+            counts = np.where(rng.random(n) < 0.15, rng.integers(1, 200, size=n), rng.integers(0, 3, size=n))
+            off = np.zeros(n + 1, dtype=np.int64)
+            off[1:] = np.cumsum(counts)
+            vals = np.concatenate([_values(rng, tname, int(c)) for c in counts]) if off[-1] else np.zeros(0, NPD[tname])
+            app.append(vals, off)
+            for v, o in enumerate(oracles):
+                o.append_many(vals[off[v]:off[v + 1]])
+        most = max(most, app.stats()["segments"])
+        if step in (40, 299, 301, 560):
+            _same_vectors(app.reader().download(), oracles, reader=True)
+    assert most <= 3 * 15 + 4, most                           # 15 per level at most, the pinned ones, not one per call
+    total = max(o.num_elements() for o in oracles) + 1000
+    _same_vectors(app.finish(total).download(), oracles, total=total)
+    assert app.stats()["segments"] == 0
+
+
 def test_series_appender_host_values_equal_device_values(cv, oracle):
     """cvec_series_appender_append_host: the same calls with the values in host memory."""
     rng = np.random.default_rng(31)
