@@ -299,10 +299,11 @@ hipError_t debug_sections_times(uint64_t *h_out) { return hipMemcpyFromSymbol(h_
 // No barriers; the only traffic between waves are the range counters.
 // TAILREF: the reference crate's tail decoder instead of the format's rule for the last octets of a vector (see
 // process_chunk); `tail` = the index pass's per-section distances to the vector's end.
-// WIDE (decode passes over small sections): a staging holds up to 64 sections instead of 16 and is worked off in
-// up to four rounds of 16, so the bytes of the next staging have up to four octet loops' time to arrive behind the
-// output stores that fill the CU's memory pipeline (one descriptor per lane instead of one per quad).
-template <int ETYPE, int MODE, int NPRED, int PIECES, int TAILREF = 0, int WIDE = 0>
+// DSHAPE (decode passes): 0 = stagings of up to 16 sections, 8-byte stores for 32-bit elements; 1 = wide stagings:
+// up to 64 sections, worked off in up to four rounds of 16, so the bytes of the next staging have up to four octet
+// loops' time to arrive behind the output stores that fill the CU's memory pipeline (one descriptor per lane instead
+// of one per quad); 2 = stagings of 16 with the 16-byte stores of the wide shape (process_chunk's PAIRS).
+template <int ETYPE, int MODE, int NPRED, int PIECES, int TAILREF = 0, int DSHAPE = 0>
 __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec_wg_per_cu(PIECES), sec_wg_per_cu(PIECES)))) void k_sections(const uint8_t *__restrict__ bytes,
                                                           const uint64_t *__restrict__ desc, uint64_t n_sections,
                                                           uint64_t sections_per_wave, PredArgs pa, SinkArgs sa,
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
     uint8_t *data = sm.data[wave];
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)data);
     const uint32_t sec = (uint32_t)lane >> 2;
-    static_assert(WIDE == 0 || MODE == MODE_DECODE, "wide stagings are a decode shape");
+    static_assert(DSHAPE == 0 || MODE == MODE_DECODE, "wide stagings and paired stores are decode shapes");
+    constexpr bool WIDE = DSHAPE == 1;
     // the section of a staging whose descriptor and plan the lane holds: its quad's, or (WIDE) its own
     const uint32_t pl = WIDE ? (uint32_t)lane : sec;
     constexpr uint32_t STAGE_SECS = WIDE ? 64u : (uint32_t)TILE;
@@ -581,10 +583,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
 #else
             const out_rsrc_t orsrc = chunk_out_rsrc<W, MODE>(out_, s_cur + j0 + sec, lane, ooff);
 #endif
-            #ifndef CVEC_WIDE_PAIRS
-#define CVEC_WIDE_PAIRS 1
-#endif
-            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF, CVEC_WIDE_PAIRS != 0>(
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF, true>(
                 data, lds_base, kind_q, rel_q, len_q, live, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from);
             if constexpr (W == 4) {
                 const unsigned long long odd_m = __ballot(odd);
@@ -648,7 +647,7 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
 #endif
             // (region offset -> LDS address; sections that end far from the vector's end keep "never")
             const int32_t tail_from = TAILREF != 0 && cur.tail_from != 0x7fffffff ? (int32_t)lds_base + cur.tail_from : 0x7fffffff;
-            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF>(
+            const bool odd = process_chunk<ETYPE, MODE, NPRED, region_span(PIECES), TAILREF, DSHAPE == 2>(
                 data, lds_base, cur.kind, cur.rel, cur.len, sec < cur.n, lane, pa, sa, res_word, mk_lo, mk_hi, orsrc, ooff, tail_from);
             // Decode: the next chunk's bytes are waited for here, behind the chunk's output stores in program order.
             // The counter of memory operations retires in order, so this wait does not include those stores, and
@@ -877,12 +876,23 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (shape_env == 3) tiny = count_only;
         if (shape_env == 4) tiny = false;
         if (tiny) small = false;
-        #ifndef CVEC_WIDE_MIN
-#define CVEC_WIDE_MIN 24
-#endif
-        bool wide = mode == MODE_DECODE && n_bytes != 0 && (n_bytes / ns) * CVEC_WIDE_MIN + 2 * 16 <= region_span(REGION_PIECES);
-        if (shape_env == 5) wide = false;
-        if (shape_env == 6) wide = mode == MODE_DECODE;
+        // Decode shapes by average section size (tools/decode_shape_probe.py, sections kernel per GiB of output;
+        // stagings of 16 with 8-byte stores / stagings of 16 with 16-byte stores / wide stagings):
+        //   u32, 189 B: 0.341 / 0.316 / 0.274 ms     313 B: 0.367 / 0.308 / 0.317     567 B: 0.373 / 0.346 / 0.355
+        //        692 B: 0.390 / 0.379 / 0.386        817 B: 0.409 / 0.420 / 0.396    1067 B: 0.451 / 0.482 / 0.444
+        //   f32, 317 B: 0.368 / 0.301 / 0.316        588 B: 0.374 / 0.341 / 0.367     845 B: 0.410 / 0.401 / 0.399
+        //   u64, 189 B: 0.277 / - / 0.246            316 B: 0.285 / - / 0.276         442 B: 0.291 / - / 0.299
+        // 32-bit elements: wide stagings up to 260 B and from 760 B per section (there a staging is one round, and
+        // what wins is the loop's form), stagings of 16 with 16-byte stores between; 64-bit elements: wide stagings
+        // up to 380 B.
+        const uint64_t avg_sec = n_bytes / ns;
+        int dshape = 0;
+        if (mode == MODE_DECODE && n_bytes != 0) {
+            if (ETYPE == CVEC_U64) dshape = avg_sec <= 380 ? 1 : 0;
+            else dshape = (avg_sec <= 260 || avg_sec > 760) ? 1 : 2;
+        }
+        bool wide = dshape == 1;
+        if (mode == MODE_DECODE && shape_env >= 5 && shape_env <= 7) { dshape = shape_env - 5; wide = dshape == 1; } // probe build
         const int wgcu = wgcu_env > 0 ? wgcu_env : (tiny ? 4 : (small ? 3 : 2));
         uint64_t nwaves_max = 256ull * wgcu * SEC_WAVES * (uint64_t)(rounds > 0 ? rounds : 1);
 #ifdef CVEC_PROBES
@@ -935,7 +945,8 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
                                                                    tag, cookie, d_gate, work, nwg < n_groups_max ? nwg : n_groups_max, epoch, keep_cached, tail)
 #define CVEC_LAUNCH_SEC_P(M, N, P, T)                                                                               \
     do {                                                                                                            \
-        if (M == MODE_DECODE && wide) CVEC_LAUNCH_SEC_PW(M, N, P, T, (M == MODE_DECODE ? 1 : 0));                  \
+        if (M == MODE_DECODE && dshape == 1) CVEC_LAUNCH_SEC_PW(M, N, P, T, (M == MODE_DECODE ? 1 : 0));           \
+        else if (M == MODE_DECODE && dshape == 2) CVEC_LAUNCH_SEC_PW(M, N, P, T, (M == MODE_DECODE && ETYPE != CVEC_U64 ? 2 : 0)); \
         else CVEC_LAUNCH_SEC_PW(M, N, P, T, 0);                                                                     \
     } while (0)
 #define CVEC_LAUNCH_SEC_T(M, N, T)                                                                                  \
@@ -961,15 +972,10 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
     default: CVEC_LAUNCH_SEC(M, 16); break;                                                                         \
     }
         if (mode == MODE_DECODE) {
-            // 32-bit output behind a blob of 5 to 35 % of its size: the pass is write-dominated, and non-temporal
-            // stores stream faster (2.25 -> 2.62 TB/s on dense u32; the second template argument is the store policy
-            // here).  Not below that: output that is mostly runs of one value (sparse vectors) loses a quarter.
-            const uint64_t raw = ns * (uint64_t)(FIXED_LEN * 4);
-            #ifndef CVEC_WIDE_NT
-#define CVEC_WIDE_NT 0
-#endif
-            const bool nt_out = ETYPE != CVEC_U64 && n_bytes * 20 >= raw && n_bytes * 20 <= raw * 7 && (!wide || CVEC_WIDE_NT);
-            if (nt_out) CVEC_LAUNCH_SEC(MODE_DECODE, 2); else CVEC_LAUNCH_SEC(MODE_DECODE, 1);
+            // (the second template argument is the store policy in this mode: 1 = default, 2 = non-temporal.  The
+            // non-temporal hint paid for dense u32 while every decode ran stagings of 16 with 8-byte stores (2.25 ->
+            // 2.62 TB/s in round 2); with the shapes above the default policy is faster everywhere, and only it is built.)
+            CVEC_LAUNCH_SEC(MODE_DECODE, 1);
         }
         else if (bucket == 1) {
             if (d_masks) { if (bits_ok) CVEC_LAUNCH_SEC(MODE_FILTER_MASKS_BITS, 1); else CVEC_LAUNCH_SEC(MODE_FILTER_MASKS, 1); }

@@ -1158,23 +1158,28 @@ def test_small_region_shape_is_chosen_by_section_size_and_agrees(cv, oracle, top
     assert onlybig.filter_count(int(big[1][9])) == int((np.concatenate(big) == big[1][9]).sum())
 
 
+@pytest.mark.parametrize("regime", ["small", "middle", "large"])
 @pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
-def test_wide_decode_stagings_vs_oracle(cv, oracle, tname):
-    """Decode passes over batches whose sections average at most a few hundred bytes stage up to 64 sections at
-    once and work them off in rounds of 16.  Section sizes are mixed so that stagings end after every possible
-    number of sections (tiny sections in runs, dense ones, a few incompressible vectors in between, ragged vector
-    ends, Null and Const sections), the batch is large enough for every wave to draw several ranges, bytes are
-    damaged in a few vectors, and both tail rules run; values, statuses and per-vector element counts against the
-    oracle."""
+def test_wide_decode_stagings_vs_oracle(cv, oracle, tname, regime):
+    """The decode pass picks its loop by the batch's average section size: wide stagings (up to 64 sections staged
+    at once and worked off in rounds of 16) for small and, with 32-bit elements, for large sections, stagings of 16
+    with paired 16-byte stores (32-bit) or plain ones (64-bit) in between.  Section sizes are mixed so that stagings
+    end after every possible number of sections (tiny sections in runs, dense ones, incompressible vectors in
+    between, ragged vector ends, Null and Const sections), bytes are damaged in a few vectors, and both tail rules
+    run; values, statuses and per-vector element counts against the oracle."""
     et, npd = ET[tname], NPD[tname]
-    rng = np.random.default_rng(4242 + et)
+    rng = np.random.default_rng(4242 + et + len(regime))
+    # which of the ten value kinds below a vector takes: mostly narrow ones, an even mix, mostly wide ones
+    kinds = {"small": (0, 0, 0, 0, 0, 1, 1, 1, 2, 3), "middle": (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), "large": (8, 9, 8, 9, 8, 9, 9, 9, 7, 0)}[regime]
     parts = []
     for v in range(2600):
         n = int(rng.integers(1, 1800))
-        kind = int(rng.integers(0, 10))
+        kind = kinds[int(rng.integers(0, 10))]
         if tname == "f32":
             if kind < 5:
                 x = (rng.integers(0, 4, size=n) * 0.5).astype(np.float32)            # few distinct bit patterns
+                if regime == "small":
+                    x = np.repeat(x[: n // 40 + 1], 40)[:n]                               # in runs: mostly empty octets
             elif kind < 8:
                 x = rng.integers(0, 1 << 12, size=n).astype(np.float32)
             else:
@@ -1200,7 +1205,15 @@ def test_wide_decode_stagings_vs_oracle(cv, oracle, tname):
         if b - a > 60:
             blob[a + (b - a) * 2 // 3] ^= 0x5a
     dev = cv.EncodedBatch(tname, blob, bo).to_device()
-    assert dev.n_sections > 6000 and dev.n_bytes // dev.n_sections * 24 + 32 <= 18 * 1024 - 64   # the wide shape's rule
+    # the launcher's rule: wide stagings up to 260 B per section (64-bit: 380) and, 32-bit only, above 760 B
+    avg = dev.n_bytes // dev.n_sections
+    assert dev.n_sections > 6000
+    if regime == "small":
+        assert avg <= 260
+    elif regime == "middle":
+        assert 380 < avg <= 760
+    else:
+        assert avg > 760
     base = {"u32": 4000000001, "u64": (1 << 63) + 77, "f32": -1.25}[tname]
     for rule in ("format", "reference"):
         for add in (None, base):
