@@ -36,6 +36,8 @@ def short(name):
         mode = MODES.get(args[1].replace("(int)", ""), args[1])
         shape = ", %s KiB%s" % (args[3].replace("(int)", ""), ", reference tail rule" if len(args) > 4 and args[4].replace("(int)", "") == "1" else "") \
             if len(args) > 3 and k == "k_sections" else ""
+        if k == "k_sections" and len(args) > 5:
+            shape += {"1": ", wide stagings", "2": ", paired stores"}.get(args[5].replace("(int)", ""), "")
         return "%s<%s, %s, %s values%s>" % (k, et, mode, args[2].replace("(int)", ""), shape)
     return "%s<%s>" % (k, ", ".join([et] + args[1:]))
 
