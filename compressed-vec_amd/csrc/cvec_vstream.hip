@@ -288,6 +288,10 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
         if (__ballot(slow) != 0) {
             bool go = slow;
             int run = 0;
+            // MODE_DECODE: runs of sections that are one value each (Null, Const) are noted here, up to two per quad
+            // and pass (neighbouring runs of one value grow into one), and written by the whole wave behind the
+            // walk: 1 KiB per store instruction instead of 64 bytes per quad.
+            uint32_t fa_slot = 0, fa_n = 0, fa_y = 0, fb_slot = 0, fb_n = 0, fb_y = 0;
             while (go) {
                 if (vec == VS_NONE) {
                     if (rvec == VS_NONE) { go = false; continue; }
@@ -391,9 +395,21 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
                         u32x4 yv;
                         if constexpr (W == 4) yv = u32x4{(uint32_t)y, (uint32_t)y, (uint32_t)y, (uint32_t)y};
                         else yv = u32x4{(uint32_t)y, (uint32_t)((uint64_t)y >> 32), (uint32_t)y, (uint32_t)((uint64_t)y >> 32)};
-                        const uint32_t o0 = slot * (uint32_t)(FIXED_LEN * W) + 16u * q;
-                        for (uint32_t j = 0; j < r * (uint32_t)(FIXED_LEN * W / 64); j++)
-                            __builtin_amdgcn_raw_buffer_store_b128(yv, orsrc, o0 + 64u * j, 0, 0);
+                        bool noted = true;
+                        if constexpr (W == 4) {
+                            if (fa_n != 0 && fa_slot + fa_n == slot && fa_y == (uint32_t)y) fa_n += r;
+                            else if (fa_n == 0) { fa_slot = slot; fa_n = r; fa_y = (uint32_t)y; }
+                            else if (fb_n != 0 && fb_slot + fb_n == slot && fb_y == (uint32_t)y) fb_n += r;
+                            else if (fb_n == 0) { fb_slot = slot; fb_n = r; fb_y = (uint32_t)y; }
+                            else noted = false;
+                        } else {
+                            noted = false;
+                        }
+                        if (!noted) { // a third run of this pass: by the quad itself
+                            const uint32_t o0 = slot * (uint32_t)(FIXED_LEN * W) + 16u * q;
+                            for (uint32_t j = 0; j < r * (uint32_t)(FIXED_LEN * W / 64); j++)
+                                __builtin_amdgcn_raw_buffer_store_b128(yv, orsrc, o0 + 64u * j, 0, 0);
+                        }
                         cnt += r * (uint32_t)FIXED_LEN;
                     } else {
                         const bool all = b0 == K_NULL ? pa.match_zero != 0 : pred_match<ETYPE, NPRED>(pa, v);
@@ -421,6 +437,25 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(vs_
                 topup = pos + S_len > wend;
                 hasS = true;
                 go = false;
+            }
+            if constexpr (MODE == MODE_DECODE && W == 4) {
+                // the noted runs, quad by quad: slot, length and value come from the quad's first lane
+                auto fill_runs = [&](uint32_t f_slot, uint32_t f_n, uint32_t f_y) {
+                    unsigned long long todo = __ballot(f_n != 0) & 0x1111111111111111ull;
+                    while (todo) {
+                        const int l = (int)__builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)f_slot, l),
+                                       nr = (uint32_t)__builtin_amdgcn_readlane((int)f_n, l),
+                                       yy = (uint32_t)__builtin_amdgcn_readlane((int)f_y, l);
+                        const u32x4 yv = u32x4{yy, yy, yy, yy};
+                        uint32_t o = s0 * (uint32_t)(FIXED_LEN * W) + 16u * (uint32_t)lane;
+                        for (uint32_t j = 0; j < nr; j++, o += (uint32_t)(FIXED_LEN * W))
+                            __builtin_amdgcn_raw_buffer_store_b128(yv, orsrc, o, 0, 0);
+                    }
+                };
+                fill_runs(fa_slot, fa_n, fa_y);
+                fill_runs(fb_slot, fb_n, fb_y);
             }
         }
         VS_PROBE(1);
