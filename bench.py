@@ -553,9 +553,16 @@ def operation_table(torch, cv):
     want_pos = int((dense_v == 3).sum().item())
     first = torch.nonzero(dense_v[:length] == 3).view(-1).cpu().numpy()
     t = _time_gpu(torch, lambda: fc.match_positions(), 5)
+    # the same with the positions left on the device, into buffers of an earlier call
+    dpos, doff = fc.match_positions_async()
+    td = _time_gpu(torch, lambda: fc.match_positions_async(dpos, doff), 20)
+    same = bool(int(doff[-1].item()) == want_pos and np.array_equal(dpos[:int(off[1])].cpu().numpy().view(np.uint32), first))
     ops["match_positions"] = {"ms": round(t * 1e3, 3), "positions": int(off[-1]), "positions_per_s": round(int(off[-1]) / t, 0),
-                              "exact": bool(int(off[-1]) == want_pos and np.array_equal(pos[:int(off[1])], first)),
-                              "shape": "%d vectors x %d u32, == 3; positions copied to the host in the timed call" % (nvec, length)}
+                              "device_resident_ms": round(td * 1e3, 4), "device_resident_positions_per_s": round(want_pos / td, 0),
+                              "exact": bool(int(off[-1]) == want_pos and np.array_equal(pos[:int(off[1])], first) and same),
+                              "shape": "%d vectors x %d u32, == 3; ms: positions copied to the host in the timed call, "
+                                       "device_resident_ms: left on the device" % (nvec, length)}
+    del dpos, doff
     del dense, sparse, dense_v, sparse_v, fc
     torch.cuda.empty_cache()
     n, length = 13107, 10000

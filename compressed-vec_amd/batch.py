@@ -399,17 +399,29 @@ class FilteredColumn:
         c.n_sections = batch.n_sections
         self.column = c
 
-    def match_positions(self):
-        """filter::match_positions for every vector: (positions uint32, pos_off uint64[n+1])."""
+    def match_positions_async(self, pos=None, pos_off=None):
+        """filter::match_positions for every vector, left on the device and not waited for: (positions int32 tensor
+        with room for every element, pos_off int64[n+1] tensor; vector v's positions are pos[pos_off[v]:pos_off[v+1]]).
+        `pos` / `pos_off`: buffers of an earlier call to write into."""
         b = self.batch
         lib = N.lib()
-        ws = torch.empty(lib.cvec_positions_workspace_bytes(b.n_sections), dtype=torch.uint8, device=b.device)
-        pos_off = torch.empty(b.n_vectors + 1, dtype=torch.int64, device=b.device)
+        need = lib.cvec_positions_workspace_bytes(b.n_sections)
+        if getattr(self, "_pos_ws", None) is None or self._pos_ws.numel() < need:
+            self._pos_ws = torch.empty(need, dtype=torch.uint8, device=b.device)
         cap = b.n_sections * FIXED_LEN
-        pos = torch.empty(max(cap, 1), dtype=torch.int32, device=b.device)
+        if pos_off is None:
+            pos_off = torch.empty(b.n_vectors + 1, dtype=torch.int64, device=b.device)
+        if pos is None:
+            pos = torch.empty(max(cap, 1), dtype=torch.int32, device=b.device)
+        assert pos.numel() >= max(cap, 1) and pos_off.numel() >= b.n_vectors + 1
         with torch.cuda.device(b.device):
             N.check(lib.cvec_match_positions_dev(C.byref(self.column), b.n_vectors, _ptr(pos_off), _ptr(pos), cap,
-                                                 _ptr(ws), ws.numel(), _stream_ptr()))
+                                                 _ptr(self._pos_ws), self._pos_ws.numel(), _stream_ptr()))
+        return pos, pos_off
+
+    def match_positions(self):
+        """filter::match_positions for every vector: (positions uint32, pos_off uint64[n+1]) on the host."""
+        pos, pos_off = self.match_positions_async()
         off = pos_off.cpu().numpy().view(np.uint64)
         return pos[:int(off[-1])].cpu().numpy().view(np.uint32), off
 

@@ -791,6 +791,13 @@ def test_multi_vector_filter_and_positions_vs_oracle(cv, oracle):
         _, wm = oracle.filter_count(oracle.U32, blobs[0][v], preds[0], return_masks=True)
         want = oracle.match_positions(wm)
         assert np.array_equal(pos[int(off[v]):int(off[v + 1])].astype(np.uint64), want), v
+    # left on the device, twice into the same buffers
+    dpos, doff = cols[0].match_positions_async()
+    dpos.fill_(-1)
+    dpos2, doff2 = cols[0].match_positions_async(dpos, doff)
+    assert dpos2 is dpos and doff2 is doff
+    assert np.array_equal(doff.cpu().numpy().view(np.uint64), off)
+    assert np.array_equal(dpos[:int(off[-1])].cpu().numpy().view(np.uint32), pos)
 
 
 @pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
