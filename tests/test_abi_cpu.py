@@ -115,9 +115,9 @@ def test_shipped_library_has_no_shift_count_in_the_last_vgpr_and_the_meant_occup
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("no llvm-objdump here")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_vgpr_hazard.py"),
-                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi6ELi[01]ELi[01]EE=4",
-                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi12ELi[01]ELi[01]EE=3",
-                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi18ELi[01]ELi[01]EE=2",
+                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi6ELi[01]ELi[012]EE=4",
+                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi12ELi[01]ELi[012]EE=3",
+                        "--expect", "k_sectionsILi[0-9]+ELi[0-9]+ELi[0-9]+ELi18ELi[01]ELi[012]EE=2",
                         "--expect", "k_vstreamILi[0-9]+ELi[0-9]+ELi[0-9]+ELi72EE=2", cv.LIB_PATH],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
