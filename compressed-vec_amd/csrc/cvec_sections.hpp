@@ -133,10 +133,11 @@ __device__ __forceinline__ void quad_mask_bytes(uint32_t a_lo, uint32_t a_hi, ui
 }
 
 typedef __amdgpu_buffer_rsrc_t out_rsrc_t;
-// Cache policy of the decoded output's stores.  Non-temporal stores are faster where the pass is write-dominated
-// (dense u32 at 0.77 B per element: 2.25 -> 2.62 TB/s) and slower where reads and writes balance (f32 XOR:
-// 2.14 -> 2.05 TB/s) or the output is long runs of one value (sparse vectors: 4.4 -> 2.7 TB/s).  In MODE_DECODE
-// the NPRED template parameter (no predicate there) carries the choice: 1 = default policy, 2 = non-temporal.
+// Cache policy of the decoded output's stores.  In MODE_DECODE the NPRED template parameter (no predicate there)
+// carries the choice: 1 = default policy, 2 = non-temporal.  The launcher only asks for 1: the non-temporal hint was
+// faster for dense u32 in a loop that staged 16 sections and stored 8 bytes per lane (2.25 -> 2.62 TB/s), slower
+// where reads and writes balance (f32 XOR: 2.14 -> 2.05 TB/s) or the output is long runs of one value (sparse
+// vectors: 4.4 -> 2.7 TB/s), and it is slower with every decode loop that exists now.
 template <int MODE, int NPRED> struct OutPolicy { static constexpr int AUX = (MODE == 1 /* MODE_DECODE */ && NPRED == 2) ? 2 : 0; };
 constexpr uint32_t OOFF_NONE = 0xffff0000u; // beyond any output descriptor (their ranges end below it): the store is dropped
 
