@@ -41,10 +41,24 @@ __global__ __launch_bounds__(256) void k_valid_sections(const uint64_t *__restri
     // a vector that failed its header checks has only K_SKIP slots
     const uint64_t a = sec_base[v], b = sec_base[v + 1];
     uint64_t s = a;
-    bool decode_error = false;
-    for (; s < b; s++) {
-        if (desc_kind(desc[s]) == K_SKIP) break;
-        if ((sec_res[s] >> 16) != 0) { decode_error = true; break; }
+    bool decode_error = false, stop = false;
+    // eight slots per round trip (the loads of a round do not depend on each other)
+    while (s < b && !stop) {
+        uint64_t d[8];
+        uint32_t r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            d[j] = s + j < b ? desc[s + j] : desc_pack(0, 0, K_SKIP);
+            r[j] = s + j < b ? sec_res[s + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (!stop) {
+                if (desc_kind(d[j]) == K_SKIP) stop = true;
+                else if ((r[j] >> 16) != 0) { decode_error = true; stop = true; }
+                else s++;
+            }
+        }
     }
     valid[v] = (uint32_t)(s - a);
     if (parse_failed) parse_failed[v] = (!decode_error && vstatus[v] != 0) ? 1 : 0;
