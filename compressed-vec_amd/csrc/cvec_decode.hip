@@ -421,8 +421,8 @@ __global__ __launch_bounds__(SEC_THREADS) __attribute__((amdgpu_waves_per_eu(sec
         // without the hint the same loads take 13 % longer (0.217 against 0.191 ms per GiB of incompressible
         // f32).  Default policy for count and mask passes over smaller blobs: a batch that is queried again and
         // again then stays in that cache from one pass to the next, index pass included (dense u32, 0.2 GB: 0.203
-        // -> 0.186 ms per pass; 0.6 GB of f32: 0.189 -> 0.187).  Decode passes keep the hint: their output would
-        // push the blob out anyway, and with the default policy dense u32 decodes a third slower.
+        // -> 0.186 ms per pass; 0.6 GB of f32: 0.189 -> 0.187).  Decode passes keep the hint above 256 MiB (see the
+        // launcher).
         if (keep_cached) {
 #pragma unroll
             for (int i = 0; i < PIECES; i++) R[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, i * 1024, 0);
@@ -932,7 +932,10 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         SinkArgs sa2 = sa;
         sa2._pad = (uint32_t)ablate; // always 0 in the product build
         // blobs up to 640 MiB are worth keeping in the last-level cache between passes (see issue_loads)
-        uint32_t keep_cached = mode != MODE_DECODE && n_bytes != 0 && n_bytes <= (640ull << 20) ? 1u : 0u;
+        // (decode passes: only blobs up to 256 MiB, the index pass's lines of which the section pass then finds in
+        // that cache although a GiB of output passes through it: dense u32 0.286 -> 0.280 ms, u64 delta 0.243 ->
+        // 0.236; a 0.6 GB blob of f32 0.339 -> 0.341)
+        uint32_t keep_cached = n_bytes != 0 && n_bytes <= ((mode != MODE_DECODE ? 640ull : 256ull) << 20) ? 1u : 0u;
         if (ablate == 6) keep_cached = 1;
         if (ablate == 7) keep_cached = 0;
         // the predicate list padded to its bucket with copies of the first value
