@@ -977,7 +977,7 @@ static void launch_sections(int mode, const uint8_t *d_bytes, const uint64_t *de
         if (mode == MODE_DECODE) {
             // (the second template argument is the store policy in this mode: 1 = default, 2 = non-temporal.  The
             // non-temporal hint paid for dense u32 while every decode ran stagings of 16 with 8-byte stores (2.25 ->
-            // 2.62 TB/s in round 2); with the shapes above the default policy is faster everywhere, and only it is built.)
+            // 2.62 TB/s); with the shapes above the default policy is faster everywhere, and only it is built.)
             CVEC_LAUNCH_SEC(MODE_DECODE, 1);
         }
         else if (bucket == 1) {
