@@ -44,11 +44,14 @@ __global__ void k_header_sections(const uint8_t *__restrict__ bytes, const uint6
     nsec[v] = c;
 }
 
-// Exclusive scan of u64 in three steps (block sums, scan of block sums, add).  SCAN_BLOCK elements
-// per workgroup; the middle step is a single workgroup looping over the block sums.
+// Exclusive scan of u64 in two steps (block sums; add): SCAN_BLOCK elements per workgroup, and every workgroup of
+// the second step adds up the sums of the blocks in front of it itself (a few hundred values at most: a batch of a
+// million sections has 512 blocks), which saves the launch of a kernel that scans the block sums.  Arrays of one
+// block take the second step alone.
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+constexpr uint32_t SCAN_SELF_BLOCKS = 2048; // up to here a block of the second step adds up its predecessors' sums itself
 
 __device__ inline uint64_t wave_incl_scan_u64(uint64_t x) {
     const int lane = threadIdx.x & 63;
@@ -92,6 +95,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_block_sums(const uint64_t
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
+// (arrays of more than SCAN_SELF_BLOCKS blocks: the block sums are scanned by one workgroup in between, as every
+// block adding up its predecessors would be quadratic)
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_of_sums(uint64_t *__restrict__ block_sums, uint64_t nblocks,
                                                                uint64_t *__restrict__ grand_total) {
     __shared__ uint64_t s_wave[4];
@@ -108,10 +113,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_of_sums(uint64_t *__restr
 }
 
 // out[i] = exclusive prefix of in[0..i); out[n] = grand total.  `in` and `out` may alias.
+// `block_sums` (the first step's totals, null for a single block): the block's offset is the sum of those in
+// front of it.
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint64_t *in, uint64_t n,
-                                                             const uint64_t *__restrict__ block_excl,
-                                                             const uint64_t *__restrict__ grand_total, uint64_t *out) {
+                                                             const uint64_t *__restrict__ block_sums, int scanned,
+                                                             uint64_t *out) {
     __shared__ uint64_t s_wave[4];
+    uint64_t before = 0;
+    if (block_sums != nullptr && scanned) {
+        before = block_sums[blockIdx.x];
+    } else if (block_sums != nullptr) {
+        uint64_t part = 0;
+        for (uint32_t b = threadIdx.x; b < blockIdx.x; b += SCAN_THREADS) part += block_sums[b];
+        block_incl_scan_u64(part, &before, s_wave);
+    }
     uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint64_t x[SCAN_ITEMS];
     uint64_t sum = 0;
@@ -122,13 +137,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint64_t *in,
     }
     uint64_t total;
     uint64_t incl = block_incl_scan_u64(sum, &total, s_wave);
-    uint64_t run = block_excl[blockIdx.x] + incl - sum;
+    uint64_t run = before + incl - sum;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         if (base + i < n) out[base + i] = run;
         run += x[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = *grand_total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = before + total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -818,9 +833,9 @@ hipError_t launch_sec_base(const uint8_t *d_bytes, const uint64_t *d_byte_off, u
     if (n == 0) return hipMemsetAsync(d_sec_base, 0, sizeof(uint64_t), stream);
     const uint32_t nblk = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
     k_header_sections<<<(uint32_t)((n + 255) / 256), 256, 0, stream>>>(d_bytes, d_byte_off, n, d_sec_base);
-    k_scan_block_sums<<<nblk, SCAN_THREADS, 0, stream>>>(d_sec_base, n, d_scratch);
-    k_scan_of_sums<<<1, SCAN_THREADS, 0, stream>>>(d_scratch, nblk, d_scratch + nblk);
-    k_scan_apply<<<nblk, SCAN_THREADS, 0, stream>>>(d_sec_base, n, d_scratch, d_scratch + nblk, d_sec_base);
+    if (nblk > 1) k_scan_block_sums<<<nblk, SCAN_THREADS, 0, stream>>>(d_sec_base, n, d_scratch);
+    if (nblk > SCAN_SELF_BLOCKS) k_scan_of_sums<<<1, SCAN_THREADS, 0, stream>>>(d_scratch, nblk, d_scratch + nblk);
+    k_scan_apply<<<nblk, SCAN_THREADS, 0, stream>>>(d_sec_base, n, nblk > 1 ? d_scratch : nullptr, nblk > SCAN_SELF_BLOCKS, d_sec_base);
     return hipGetLastError();
 }
 
@@ -830,9 +845,9 @@ hipError_t launch_exclusive_scan(const uint64_t *d_in, uint64_t n, uint64_t *d_o
                                  hipStream_t stream) {
     if (n == 0) return hipMemsetAsync(d_out, 0, sizeof(uint64_t), stream);
     const uint32_t nblk = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    k_scan_block_sums<<<nblk, SCAN_THREADS, 0, stream>>>(d_in, n, d_scratch);
-    k_scan_of_sums<<<1, SCAN_THREADS, 0, stream>>>(d_scratch, nblk, d_scratch + nblk);
-    k_scan_apply<<<nblk, SCAN_THREADS, 0, stream>>>(d_in, n, d_scratch, d_scratch + nblk, d_out);
+    if (nblk > 1) k_scan_block_sums<<<nblk, SCAN_THREADS, 0, stream>>>(d_in, n, d_scratch);
+    if (nblk > SCAN_SELF_BLOCKS) k_scan_of_sums<<<1, SCAN_THREADS, 0, stream>>>(d_scratch, nblk, d_scratch + nblk);
+    k_scan_apply<<<nblk, SCAN_THREADS, 0, stream>>>(d_in, n, nblk > 1 ? d_scratch : nullptr, nblk > SCAN_SELF_BLOCKS, d_out);
     return hipGetLastError();
 }
 

@@ -1243,6 +1243,32 @@ def test_wide_decode_stagings_vs_oracle(cv, oracle, tname, regime):
             assert np.array_equal(_bits(got)[keep], _bits(want)[keep]), (rule, add)
 
 
+def test_batches_of_millions_of_vectors_take_the_long_scan(cv):
+    """The exclusive scans behind sec_base, the encoder's offsets and match_positions add up block sums inside
+    their second kernel for up to 2048 blocks of 2048 entries and scan them in a kernel of their own beyond:
+    4.3 million one-element vectors reach the second form; counts, decoded values and positions against the
+    values."""
+    import torch
+    n = 4_300_000
+    vals = (torch.arange(n, device="cuda", dtype=torch.int64) * 2654435761 % 7).to(torch.int32)
+    eo = torch.arange(n + 1, device="cuda", dtype=torch.int64)
+    dev = cv.encode_device("u32", vals, eo)
+    assert dev.n_vectors == n and dev.n_sections == n
+    want = int((vals == 3).sum().item())
+    total, per = dev.filter_count(3, per_vector=True)
+    assert total == want and int(np.asarray(per).sum()) == want
+    out = torch.empty(n * 256, dtype=torch.int32, device="cuda")
+    dev.decode_async(out)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(n, 256)[:, 0], vals) and int(out.view(n, 256)[:, 1:].abs().sum().item()) == 0
+    del out
+    pos, off = dev.filter_masks(3).match_positions_async()
+    off = off.cpu().numpy()
+    assert int(off[-1]) == want and int(pos[:want].abs().sum().item()) == 0      # every match is element 0 of its vector
+    hit = np.flatnonzero((vals == 3).cpu().numpy())
+    assert np.array_equal(np.flatnonzero(np.diff(off.astype(np.int64))), hit)
+
+
 def test_full_size_properties_cfg5_shape(cv):
     """1 Mi elements per call at the benchmark's vector shape (2048-element f32 vectors): encode →
     decode is the identity on bits, counts are additive over predicates that partition the values,
