@@ -484,20 +484,26 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
         m_dst = HEADER_BYTES * ((uint64_t)sec_vec[slot] + 1) + at;
         m_size = (uint32_t)(sec_scan[slot + 1] - at);
     }
-    const int cnt = __popcll(__ballot(m.valid != 0));
     // A section of one byte is a Null section (every other kind takes three bytes or more): its values are all
-    // zero and are not read again.  A descriptor of no elements makes the load a no-op that returns zeros, and
-    // zeros plan as Null below.
-    const uint32_t m_avail = m_size == 1 ? 0u : m.avail;
+    // zero and are not read again.  Every lane writes the byte of its own Null section here
+    // (NullFixedSect::write, src/section.rs:440-443), and the loop below takes the other sections only.
+    if (m.valid != 0 && m_size == 1) bytes[m_dst] = (uint8_t)K_NULL;
+    uint64_t todo = __ballot(m.valid != 0 && m_size != 1);
+    if (todo == 0) return;
+    int r = __builtin_ctzll(todo);
+    todo &= todo - 1;
     U x[4], xn[4];
-    load_section<ETYPE>(values, lane_val(m.e0, 0), lane_val(m.valid, 0), lane_val(m_avail, 0), lane, x);
-    for (int r = 0; r < cnt; r++) {
-        load_section<ETYPE>(values, lane_val(m.e0, r + 1), lane_val(m.valid, r + 1), lane_val(m_avail, r + 1), lane, xn); // lane cnt: nothing to load
+    load_section<ETYPE>(values, lane_val(m.e0, r), lane_val(m.valid, r), lane_val(m.avail, r), lane, x);
+    for (;;) {
+        // the next section that has bytes of its own; behind the last one a descriptor of no elements (a no-op load)
+        const bool more = todo != 0;
+        const int rn = more ? __builtin_ctzll(todo) : r;
+        todo &= todo - 1;
+        load_section<ETYPE>(values, lane_val(m.e0, rn), lane_val(m.valid, rn), more ? lane_val(m.avail, rn) : 0u, lane, xn);
         const uint64_t dst_off = lane_val(m_dst, r);
         const uint32_t size = lane_val(m_size, r);
         uint8_t *dst = bytes + dst_off;
-        SecPlan<U> p = {(uint32_t)K_NULL, 0, 0, 0};
-        if (size != 1) p = plan_section<ETYPE>(x, lane); // one byte: Null, known from the sizes pass
+        const SecPlan<U> p = plan_section<ETYPE>(x, lane);
         if (p.kind == K_NULL) { // NullFixedSect::write (src/section.rs:440-443)
             if (lane == 0) dst[0] = (uint8_t)K_NULL;
         } else if (p.kind == K_CONST) { // ConstFixedSect::write (src/section.rs:795-803): values[0], not min
@@ -535,6 +541,8 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) x[i] = xn[i];
+        if (!more) break;
+        r = rn;
     }
 }
 
