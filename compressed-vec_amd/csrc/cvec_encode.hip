@@ -486,9 +486,17 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(const typename EncT<ET
     }
     // A section of one byte is a Null section (every other kind takes three bytes or more): its values are all
     // zero and are not read again.  Every lane writes the byte of its own Null section here
-    // (NullFixedSect::write, src/section.rs:440-443), and the loop below takes the other sections only.
-    if (m.valid != 0 && m_size == 1) bytes[m_dst] = (uint8_t)K_NULL;
-    uint64_t todo = __ballot(m.valid != 0 && m_size != 1);
+    // (NullFixedSect::write, src/section.rs:440-443), and the loop below takes the sections with octets only.
+    // Likewise a section of 1 + W bytes is a Const section (ConstFixedSect::write, src/section.rs:795-803: the type
+    // byte and values[0]; sections with octets take more than 30 bytes), for which one value is read.
+    const bool own_null = m.valid != 0 && m_size == 1, own_const = m.valid != 0 && m_size == 1 + W;
+    if (own_null) bytes[m_dst] = (uint8_t)K_NULL;
+    if (own_const) {
+        const U first = values[m.e0];
+        bytes[m_dst] = (uint8_t)K_CONST;
+        if constexpr (W == 4) *(u32u *)(bytes + m_dst + 1) = first; else *(u64u *)(bytes + m_dst + 1) = first;
+    }
+    uint64_t todo = __ballot(m.valid != 0 && !own_null && !own_const);
     if (todo == 0) return;
     int r = __builtin_ctzll(todo);
     todo &= todo - 1;

@@ -103,6 +103,46 @@ def test_encode_bytes_bit_exact_vs_oracle(cv, oracle, tname):
 
 
 @pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
+def test_encode_runs_of_null_and_const_sections_vs_oracle(cv, oracle, tname):
+    """Sections without octets (Null: one byte, src/section.rs:440-443; Const: type byte + value, :795-803) are
+    written by the emit pass outside its loop over sections with octets: whole runs of them, single ones between
+    value sections, at the end of a vector (a short last section is padded with zeros: Null only if its values are
+    zero), signed zeros and NaN constants for f32."""
+    rng = np.random.default_rng(4100 + ET[tname])
+    dt = NPD[tname]
+    vals, off = [], [0]
+    for v in range(260):
+        nsec = int(rng.integers(1, 45))
+        pieces = []
+        for s in range(nsec):
+            k = 256 if s + 1 < nsec or rng.random() < 0.5 else int(rng.integers(1, 256))
+            kind = int(rng.integers(0, 6)) if v % 3 else int(rng.integers(0, 3))
+            if kind == 0:
+                p = np.zeros(k, dtype=dt)
+            elif kind == 1:
+                c = rng.integers(1, 1 << 31) if tname != "f32" else np.float32(rng.normal())
+                p = np.full(k, c, dtype=dt)
+            elif kind == 2 and tname == "f32":
+                bits = rng.choice(np.array([0x80000000, 0x7fc00000, 0x7f800000, 0x00000001], dtype=np.uint32))
+                p = np.full(k, bits, dtype=np.uint32).view(np.float32)
+            elif kind == 2:
+                p = np.full(k, np.iinfo(dt).max, dtype=dt)
+            elif tname == "f32":
+                p = (rng.integers(0, 1 << 12, size=k) / 1.4).astype(np.float32)
+            else:
+                p = rng.integers(0, 1 << int(rng.integers(1, 30)), size=k).astype(dt)
+            pieces.append(p)
+        x = np.concatenate(pieces)
+        vals.append(x)
+        off.append(off[-1] + x.size)
+    flat, eo = np.concatenate(vals), np.array(off, dtype=np.uint64)
+    want_blob, want_off = oracle.batch_encode(ET[tname], flat, eo)
+    got = cv.encode_batch(tname, flat, eo)
+    assert np.array_equal(got.byte_off, want_off)
+    assert np.array_equal(got.blob, want_blob)
+
+
+@pytest.mark.parametrize("tname", ["u32", "u64", "f32"])
 def test_decode_bit_exact_vs_oracle(cv, oracle, tname):
     rng = np.random.default_rng(200 + ET[tname])
     vals, eo = _random_vectors(rng, tname, 300)
